@@ -1,0 +1,125 @@
+/*
+ * v3d_hip.h -- C ABI of libv3d_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * hot path of video_3d_pipeline (SBS frame -> disparity -> 4K depth).
+ *
+ * The reference has no FFI of its own (pure Python calling OpenCV / ffmpeg); each entry point
+ * below replaces one OpenCV / NumPy / ffmpeg call site of the reference and is what a ctypes
+ * binding in the reference's depth.py / upscale.py would bind:
+ *
+ *   v3d_sbs_to_gray        depth.py:250-268 split_sbs_frame (cv2.resize INTER_LANCZOS4) +
+ *                          depth.py:274-275, 337-338 cvtColor BGR->RGB->GRAY
+ *   v3d_sgbm_create        depth.py:315-325 cv2.StereoSGBM_create(...)
+ *   v3d_sgbm_compute[_batch]  depth.py:341 stereo.compute(left_gray, right_gray) -> int16 x16
+ *   v3d_disp_to_depth      depth.py:341 .astype(float32)/16.0 and depth.py:374 clamp <=0 -> 0
+ *   v3d_depth_to_u16       depth.py:397-406 save_depth_map min-max normalisation to uint16
+ *   v3d_guided_upscale     upscale.py:21-73 upscale_depth_maps_ffmpeg (`scale` filter), re-specified
+ *                          as guided-filter joint upsampling
+ *   v3d_corr_lookup        CREStereo recurrent correlation lookup (BASELINE.json config 4; the
+ *                          reference only names it: depth.py:1, CREStereo_model.txt)
+ *
+ * Conventions
+ *  - every image/volume pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor's
+ *    data_ptr()); nothing here allocates on the steady-state path: workspaces belong to the handle
+ *    and are sized at create time;
+ *  - `stream` is a hipStream_t passed as void*; calls enqueue work and do NOT synchronise;
+ *  - return 0 on success, negative on error; v3d_last_error() returns the thread-local message;
+ *  - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef V3D_HIP_H
+#define V3D_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3D_OK 0
+#define V3D_ERR_ARG (-1)
+#define V3D_ERR_HIP (-2)
+#define V3D_ERR_UNSUPPORTED (-3)
+
+#define V3D_MODE_SGBM 0   /* 5 paths, single pass: cv2.STEREO_SGBM_MODE_SGBM (the reference's default) */
+#define V3D_MODE_HH   1   /* 8 paths, two passes: cv2.STEREO_SGBM_MODE_HH */
+
+typedef struct v3d_sgbm v3d_sgbm;
+
+/* mirrors the keyword arguments of cv2.StereoSGBM_create (depth.py:315-325) */
+typedef struct {
+    int minDisparity;       /* must be 0 */
+    int numDisparities;     /* must be 64 in this build */
+    int blockSize;          /* must be 5 in this build */
+    int P1, P2;
+    int disp12MaxDiff;
+    int preFilterCap;
+    int uniquenessRatio;
+    int speckleWindowSize;
+    int speckleRange;
+    int mode;               /* V3D_MODE_SGBM / V3D_MODE_HH */
+} v3d_sgbm_params;
+
+/* fills the parameter block depth.py:315-325 uses */
+void v3d_sgbm_default_params(v3d_sgbm_params* p);
+
+/* create a matcher whose workspaces hold up to max_batch frames of max_width x max_height */
+int v3d_sgbm_create(const v3d_sgbm_params* params, int device, int max_width, int max_height,
+                    int max_batch, v3d_sgbm** out);
+void v3d_sgbm_destroy(v3d_sgbm* h);
+/* bytes of device workspace the handle owns */
+size_t v3d_sgbm_workspace_bytes(const v3d_sgbm* h);
+
+/* one frame: left/right gray u8 [H][pitch], disp16 out int16 [H][W] (value x16, -16 invalid) */
+int v3d_sgbm_compute(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
+                     int W, int H, int pitch, int16_t* disp16_out, void* stream);
+/* n frames: frame f at left_gray + f*frame_stride (bytes), output frame f at disp16_out + f*W*H */
+int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
+                           int n, int W, int H, int pitch, size_t frame_stride,
+                           int16_t* disp16_out, void* stream);
+
+/* stage exports used by the parity tests (same inputs as v3d_sgbm_compute, one frame) */
+/* cost volume C[y][x-64][d] int16, P2 folded in */
+int v3d_sgbm_debug_cost_volume(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
+                               int W, int H, int pitch, int16_t* C_out, void* stream);
+/* raw disparity before median/speckle (after WTA, uniqueness, sub-pixel, L-R check) and,
+   if S_out != NULL, the aggregated volume S[y][x-64][d] */
+int v3d_sgbm_debug_raw(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
+                       int W, int H, int pitch, int16_t* disp16_out, int16_t* S_out, void* stream);
+int v3d_median3x3_i16(const int16_t* src, int W, int H, int16_t* dst, void* stream);
+/* labels_ws: device scratch of 2*W*H int32 */
+int v3d_filter_speckles(int16_t* img, int W, int H, int newVal, int maxSpeckleSize, int maxDiff,
+                        int32_t* labels_ws, void* stream);
+
+/* SBS BGR u8 [H][pitch] (W*3 payload bytes per row) -> gray left/right.
+   unsqueeze != 0: outputs are W x H (Lanczos4 x2 horizontal); else (W/2) x H. W must be even. */
+int v3d_sbs_to_gray(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze,
+                    uint8_t* left_gray, uint8_t* right_gray, void* stream);
+/* the BGR halves themselves (split_sbs_frame's return value), [H][outW][3] */
+int v3d_split_sbs(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze,
+                  uint8_t* left_bgr, uint8_t* right_bgr, void* stream);
+
+int v3d_disp_to_depth(const int16_t* disp16, size_t n, float* depth_out, void* stream);
+/* minmax_ws: device scratch of >= 2 floats */
+int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, float* minmax_ws, void* stream);
+
+/* guided-filter joint upsampling: depth_lo f32 [Hlo][Wlo], guide u8 luma [Hhi][Whi] -> out f32 [Hhi][Whi].
+   ws: device scratch of v3d_guided_upscale_ws_bytes(Whi, Hhi) bytes */
+size_t v3d_guided_upscale_ws_bytes(int Whi, int Hhi);
+int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int Whi, int Hhi,
+                       int r, float eps, float* out, void* ws, void* stream);
+/* BGR [H][W][3] u8 -> luma u8 with the same weights as cvtColor */
+int v3d_bgr_to_gray(const uint8_t* bgr, size_t n_pixels, uint8_t* gray, void* stream);
+
+/* CREStereo-style local group correlation on the matrix cores.
+   fl, fr: bf16 [h][w][C] (channel-last), flow: f32 [2][h][w], out: f32 [G*9][h][w];
+   C = 64*G; pattern 0 = 1x9, 1 = 3x3.  ws: scratch of v3d_corr_ws_bytes(C,h,w) bytes */
+size_t v3d_corr_ws_bytes(int C, int h, int w);
+int v3d_corr_lookup(const uint16_t* fl_bf16, const uint16_t* fr_bf16, const float* flow,
+                    int C, int h, int w, int G, int pattern, float* out, void* ws, void* stream);
+
+const char* v3d_last_error(void);
+const char* v3d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,49 @@
+"""GPU parity of the MFMA correlation lookup (BASELINE config 4) against the fp32 oracle.
+bf16 inputs, f32 accumulate; the warped right features are rounded to bf16 once: tolerance 2e-2 of the
+output scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("pattern", [0, 1])
+@pytest.mark.parametrize("h,w,G", [(12, 48, 4), (9, 37, 2), (30, 64, 4)])
+def test_corr_matches_oracle(native, oracle, pattern, h, w, G):
+    rng = np.random.default_rng(h * w + pattern)
+    C = 64 * G
+    fl = _bf16_round(rng.normal(0, 1, (C, h, w)).astype(np.float32))
+    fr = _bf16_round(rng.normal(0, 1, (C, h, w)).astype(np.float32))
+    flow = rng.uniform(-3, 3, (2, h, w)).astype(np.float32)
+    want = oracle.corr_lookup(fl, fr, flow, G, pattern)
+    fl_d = torch.from_numpy(fl).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
+    fr_d = torch.from_numpy(fr).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
+    got = native.corr_lookup(fl_d, fr_d, torch.from_numpy(flow).cuda(), G, pattern).cpu().numpy()
+    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= tol, f"max abs err {np.abs(got - want).max():.4e} (tol {tol:.3e})"
+
+
+def test_one_hot_channels_pick_shifted_copies(native):
+    """one-hot features + zero flow: corr picks the (clamped) shifted copies (SURVEY 8c known-answer 12)"""
+    h, w, G = 4, 32, 1
+    C = 64
+    fl = np.zeros((h, w, C), np.float32)
+    fr = np.zeros((h, w, C), np.float32)
+    fl[..., 0] = 1.0
+    fr[..., 0] = np.arange(w, dtype=np.float32)[None, :]          # exactly representable in bf16 up to 256
+    out = native.corr_lookup(torch.from_numpy(fl).to("cuda", torch.bfloat16), torch.from_numpy(fr).to("cuda", torch.bfloat16),
+                             torch.zeros((2, h, w), device="cuda"), G, 0).cpu().numpy()
+    for k in range(9):
+        want = np.clip(np.arange(w) + k - 4, 0, w - 1) / 64.0
+        assert np.allclose(out[k], want[None, :], atol=1e-6), k
+
+
+def test_rejects_bad_channels(native):
+    a = torch.zeros((4, 16, 48), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(native.NativeError):
+        native.corr_lookup(a, a, torch.zeros((2, 4, 16), device="cuda"), 1, 0)

@@ -1,0 +1,84 @@
+"""GPU parity of the guided-filter upscaler (upscale.py:21-73 re-specified) against the
+float64 oracle.  Tolerance (BASELINE.json north_star): 1e-3 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _rel_err(got, want):
+    scale = np.maximum(np.abs(want), 1e-6 * max(float(np.abs(want).max()), 1e-30))
+    return np.abs(got - want) / scale
+
+
+def _case(seed, Wlo, Hlo, scale=2):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    depth = gaussian_filter(rng.uniform(0, 63, (Hlo, Wlo)), 3.0).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.05] = 0.0
+    guide = np.clip(gaussian_filter(rng.uniform(0, 255, (Hlo * scale, Wlo * scale)), 2.0) * 1.5 - 60, 0, 255).astype(np.uint8)
+    return depth, guide
+
+
+@pytest.mark.parametrize("Wlo,Hlo,r,eps", [(96, 54, 8, 1e-3), (131, 77, 8, 1e-3), (160, 90, 4, 1e-2), (100, 60, 16, 1e-4)])
+def test_guided_upscale_matches_oracle(native, oracle, Wlo, Hlo, r, eps):
+    depth, guide = _case(Wlo + Hlo, Wlo, Hlo)
+    want = oracle.guided_upscale(depth, guide, r, eps)
+    got = native.guided_upscale(native.to_device(depth), native.to_device(guide), r, eps).cpu().numpy().astype(np.float64)
+    err = _rel_err(got, want)
+    assert err.max() <= RTOL, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_non_integer_scale(native, oracle):
+    depth, _ = _case(3, 100, 60)
+    rng = np.random.default_rng(4)
+    guide = rng.integers(0, 256, (150, 230), dtype=np.uint8)
+    want = oracle.guided_upscale(depth, guide, 8, 1e-3)
+    got = native.guided_upscale(native.to_device(depth), native.to_device(guide), 8, 1e-3).cpu().numpy()
+    assert _rel_err(got.astype(np.float64), want).max() <= RTOL
+
+
+def test_constant_guide_is_double_box_of_p(native, oracle):
+    """I const => a = 0, b = box(p), q = box(box(p))   (SURVEY 8c known-answer 11)"""
+    depth, _ = _case(9, 80, 50)
+    guide = np.full((100, 160), 77, np.uint8)
+    got = native.guided_upscale(native.to_device(depth), native.to_device(guide), 8, 1e-3).cpu().numpy()
+    p = oracle.bilinear_resize(depth, 160, 100)
+    from scipy.ndimage import uniform_filter
+
+    def box(a, r=8):
+        ones = np.ones_like(a)
+        s = uniform_filter(a, 2 * r + 1, mode="constant") * (2 * r + 1) ** 2
+        c = uniform_filter(ones, 2 * r + 1, mode="constant") * (2 * r + 1) ** 2
+        return s / c
+
+    want = box(box(p))
+    assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+
+
+def test_affine_in_guide_reproduced(native):
+    """p = alpha*I + beta with eps -> 0 gives q ~= p"""
+    rng = np.random.default_rng(12)
+    guide = rng.integers(0, 256, (64, 96), dtype=np.uint8)
+    p = (guide.astype(np.float32) / 255.0) * 40.0 + 5.0
+    got = native.guided_upscale(native.to_device(p), native.to_device(guide), 4, 1e-9).cpu().numpy()   # scale 1: bilinear is identity
+    assert np.abs(got - p).max() < 5e-2
+
+
+def test_full_4k_size(native, oracle):
+    from video_3d_pipeline import synthetic as syn
+    depth = syn.gt_disparity(1920, 1080).astype(np.float32)
+    guide = syn.guide_frame(1920, 1080, 0)
+    got = native.guided_upscale(native.to_device(depth), native.to_device(guide), 8, 1e-3).cpu().numpy()
+    assert got.shape == (2160, 3840) and np.isfinite(got).all()
+    want = oracle.guided_upscale(depth, guide, 8, 1e-3)
+    assert _rel_err(got.astype(np.float64), want).max() <= RTOL
+
+
+def test_rejects_bad_radius(native):
+    d = native.to_device(np.zeros((10, 10), np.float32))
+    g = native.to_device(np.zeros((20, 20), np.uint8))
+    with pytest.raises(native.NativeError):
+        native.guided_upscale(d, g, 40, 1e-3)

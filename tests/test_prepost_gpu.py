@@ -1,0 +1,58 @@
+"""GPU parity of the steps either side of the matcher: depth.py:250-268 (split + Lanczos4 unsqueeze),
+:274-275/:337-338 (gray), :341/:374 (/16 + clamp), :397-406 (min-max to uint16).  Integer work: bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import mismatch_report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("W,H", [(64, 8), (322, 45), (960, 540), (1920, 1080)])
+@pytest.mark.parametrize("unsqueeze", [True, False])
+def test_sbs_to_gray_bit_exact(native, oracle, W, H, unsqueeze):
+    rng = np.random.default_rng(W * 3 + H)
+    sbs = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    wl, wr = oracle.sbs_to_gray(sbs, unsqueeze)
+    gl, gr = native.sbs_to_gray(native.to_device(sbs), unsqueeze)
+    assert not mismatch_report(gl.cpu().numpy(), wl, "left gray"), mismatch_report(gl.cpu().numpy(), wl, "left gray")
+    assert not mismatch_report(gr.cpu().numpy(), wr, "right gray"), mismatch_report(gr.cpu().numpy(), wr, "right gray")
+
+
+def test_split_sbs_bgr_bit_exact(native, oracle):
+    rng = np.random.default_rng(5)
+    sbs = rng.integers(0, 256, (37, 130, 3), dtype=np.uint8)
+    # saturating content: hard black/white edges overshoot under Lanczos
+    sbs[:, 20:40] = 255
+    sbs[:, 40:60] = 0
+    for unsq in (True, False):
+        wl, wr = oracle.split_sbs(sbs, unsq)
+        gl, gr = native.split_sbs(native.to_device(sbs), unsq)
+        assert not mismatch_report(gl.cpu().numpy(), wl, "left bgr")
+        assert not mismatch_report(gr.cpu().numpy(), wr, "right bgr")
+
+
+def test_odd_width_raises_value_error(native):
+    sbs = native.to_device(np.zeros((4, 7, 3), np.uint8))
+    with pytest.raises(ValueError):
+        native.sbs_to_gray(sbs)
+
+
+def test_bgr_to_gray(native, oracle):
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (33, 71, 3), dtype=np.uint8)
+    got = native.bgr_to_gray(native.to_device(img)).cpu().numpy()
+    assert not mismatch_report(got, oracle.bgr_to_gray(img), "gray")
+
+
+def test_disp_to_depth_and_u16(native, oracle):
+    rng = np.random.default_rng(7)
+    d = (rng.integers(-1, 64 * 16, (200, 333))).astype(np.int16)
+    d[rng.random(d.shape) < 0.2] = -16
+    dep = native.disp_to_depth(native.to_device(d))
+    want = oracle.disp_to_depth(d)
+    assert np.array_equal(dep.cpu().numpy(), want)
+    u = native.depth_to_u16(dep).cpu().numpy().view(np.uint16)
+    assert not mismatch_report(u, oracle.depth_to_u16(want), "u16")
+    flat = native.to_device(np.full((5, 9), 3.25, np.float32))
+    assert (native.depth_to_u16(flat).cpu().numpy() == 0).all()

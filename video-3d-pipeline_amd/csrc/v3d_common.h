@@ -1,0 +1,71 @@
+// v3d_common.h -- shared helpers for libv3d_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/v3d_hip.h"
+
+#define V3D_D 64              // numDisparities this build is specialised for (one wavefront of d)
+#define V3D_MAX_COST 32767
+#define V3D_INVALID16 (-16)   // (minDisparity - 1) * 16
+
+void v3d_set_error(const char* fmt, ...);
+
+#define V3D_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            v3d_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return V3D_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define V3D_LAUNCH_CHECK()                                                               \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            v3d_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return V3D_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+static inline int v3d_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---- packed 2 x int16 arithmetic on one VGPR (v_pk_*_i16 / _u16 on gfx950) ----
+typedef short v3d_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short v3d_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v3d_s16x2 as_s(uint32_t a) { return __builtin_bit_cast(v3d_s16x2, a); }
+__device__ __forceinline__ v3d_u16x2 as_us(uint32_t a) { return __builtin_bit_cast(v3d_u16x2, a); }
+__device__ __forceinline__ uint32_t as_u(v3d_s16x2 a) { return __builtin_bit_cast(uint32_t, a); }
+__device__ __forceinline__ uint32_t as_u(v3d_u16x2 a) { return __builtin_bit_cast(uint32_t, a); }
+
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_min(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u((v3d_s16x2)(as_s(a) + as_s(b))); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u((v3d_s16x2)(as_s(a) - as_s(b))); }
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_sub_sat(as_us(a), as_us(b))); }
+__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_min(as_us(a), as_us(b))); }
+__device__ __forceinline__ uint32_t pk_shr_u(uint32_t a, int n) { return as_u((v3d_u16x2)(as_us(a) >> (unsigned short)n)); }
+__device__ __forceinline__ uint32_t pk_bcast(int v) { return ((uint32_t)v & 0xFFFFu) * 0x00010001u; }
+
+// ({hi,lo} >> sh) & 0xffffffff  (v_alignbit_b32)
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// ---- DPP lane movement (CDNA4 is a gfx9-family ISA: row_* controls act inside 16-lane rows) ----
+#define V3D_DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define V3D_DPP_ROW_SHL(n) (0x100 + (n))   // lane i reads lane i+n
+#define V3D_DPP_ROW_SHR(n) (0x110 + (n))   // lane i reads lane i-n
+#define V3D_DPP_ROW_MIRROR 0x140
+#define V3D_DPP_ROW_HALF_MIRROR 0x141
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
+{
+    // lanes whose source is outside the row keep `old` (bound_ctrl = 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+#endif

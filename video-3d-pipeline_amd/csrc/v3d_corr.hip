@@ -1,0 +1,134 @@
+// v3d_corr.hip -- CREStereo-style local group correlation lookup on the matrix cores
+// (BASELINE.json config 4; SURVEY.md 8a-12 / Appendix B.2 form A).  The reference only *names*
+// CREStereo (depth.py:1, CREStereo_model.txt); there is no reference code for this step.
+//
+//   fr'            = bilinear sample of fr at (x + flow_x, y + flow_y), zeros outside   (k_corr_warp)
+//   out[g*9+k,y,x] = (1/64) * sum_{c in group g} fl[y,x,c] * fr'[clamp(y+dy), clamp(x+dx), c]
+//
+// It is a dense feature-channel contraction, so it runs on MFMA: one wave owns a 16-pixel row tile;
+// per group, A = fl tile (16 px x 64 ch), B = the 32 warped positions x0-4 .. x0+27 (two 16-wide
+// N tiles), 2 k-steps of v_mfma_f32_16x16x32_bf16 each; the 9 wanted diagonals of the 16x32 product
+// are picked out of the accumulators.  Arithmetic intensity is ~4 flop/B: the kernel is HBM/L2
+// bound, MFMA only removes the VALU bottleneck.
+#include "v3d_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// one thread = one pixel x one 8-channel chunk
+__global__ __launch_bounds__(256) void k_corr_warp(const unsigned short* __restrict__ fr, const float* __restrict__ flow,
+                                                   int C, int h, int w, unsigned short* __restrict__ out)
+{
+    const int chunks = C >> 3;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)h * w * chunks) return;
+    const int ch = (int)(gid % chunks);
+    const size_t pix = gid / chunks;
+    const int x = (int)(pix % w), y = (int)(pix / w);
+    const float sx = x + flow[pix], sy = y + flow[(size_t)h * w + pix];
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float wx = sx - x0f, wy = sy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int xx = x0 + i, yy = y0 + j;
+            if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+            const float wgt = (i ? wx : 1.f - wx) * (j ? wy : 1.f - wy);
+            const uint4 v = *reinterpret_cast<const uint4*>(fr + ((size_t)yy * w + xx) * C + ch * 8);
+            const unsigned u[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc[2 * k] += bf2f((unsigned short)(u[k] & 0xFFFFu)) * wgt;
+                acc[2 * k + 1] += bf2f((unsigned short)(u[k] >> 16)) * wgt;
+            }
+        }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = (__bf16)acc[k];
+    *reinterpret_cast<bf16x8*>(out + pix * C + ch * 8) = o;
+}
+
+// one wave = 16 consecutive pixels of one row, all groups; 4 waves per block
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k_corr(const unsigned short* __restrict__ fl, const unsigned short* __restrict__ frw,
+                                              int C, int h, int w, int G, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int xtiles = (w + 15) >> 4;
+    const int gw = blockIdx.x * 4 + wib;
+    if (gw >= xtiles * h) return;
+    const int y = gw / xtiles, x0 = (gw - y * xtiles) << 4;
+    const int r16 = lane & 15, q = lane >> 4;                 // MFMA operand row/col and k-quarter
+    const size_t hw = (size_t)h * w;
+    const float scale = 1.0f / 64.0f;
+    constexpr int NROW = PATTERN == 0 ? 1 : 3;
+
+    const int xa = min(x0 + r16, w - 1);                       // A operand: pixel x0 + r16
+    for (int g = 0; g < G; g++) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+            a[ks] = *reinterpret_cast<const bf16x8*>(fl + ((size_t)y * w + xa) * C + g * 64 + ks * 32 + q * 8);
+#pragma unroll
+        for (int ry = 0; ry < NROW; ry++) {
+            const int dy = PATTERN == 0 ? 0 : ry - 1;
+            const int yy = min(max(y + dy, 0), h - 1);
+            f32x4 acc[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                acc[n] = (f32x4){ 0.f, 0.f, 0.f, 0.f };
+                const int xb = min(max(x0 - 4 + n * 16 + r16, 0), w - 1);   // B operand: warped position
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(frw + ((size_t)yy * w + xb) * C + g * 64 + ks * 32 + q * 8);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], b, acc[n], 0, 0, 0);
+                }
+            }
+            // accumulator element (reg r) of this lane: pixel i = 4q + r, position column j = r16 of tile n
+            //   -> window offset k = j - i + 16 n  (dx = k - 4), wanted when 0 <= k <= 8 (1x9) or 3 <= k <= 5 (3x3)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = 4 * q + r;
+                    const int k = r16 - i + 16 * n;
+                    const int x = x0 + i;
+                    bool want; int plane;
+                    if (PATTERN == 0) { want = (k >= 0 && k <= 8); plane = g * 9 + k; }
+                    else { want = (k >= 3 && k <= 5); plane = g * 9 + ry * 3 + (k - 3); }
+                    if (want && x < w) out[(size_t)plane * hw + (size_t)y * w + x] = acc[n][r] * scale;
+                }
+        }
+    }
+}
+
+extern "C" size_t v3d_corr_ws_bytes(int C, int h, int w)
+{
+    if (C < 1 || h < 1 || w < 1) return 0;
+    return (size_t)C * h * w * sizeof(unsigned short);
+}
+
+extern "C" int v3d_corr_lookup(const uint16_t* fl, const uint16_t* fr, const float* flow, int C, int h, int w,
+                               int G, int pattern, float* out, void* ws, void* stream)
+{
+    if (!fl || !fr || !flow || !out || !ws) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (G < 1 || C != 64 * G) { v3d_set_error("need C == 64*G channels (got C=%d, G=%d)", C, G); return V3D_ERR_UNSUPPORTED; }
+    if (h < 1 || w < 1) { v3d_set_error("bad geometry"); return V3D_ERR_ARG; }
+    if (pattern != 0 && pattern != 1) { v3d_set_error("pattern must be 0 (1x9) or 1 (3x3)"); return V3D_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* frw = reinterpret_cast<unsigned short*>(ws);
+    const size_t nthreads = (size_t)h * w * (C / 8);
+    hipLaunchKernelGGL(k_corr_warp, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, fr, flow, C, h, w, frw);
+    const int waves = ((w + 15) / 16) * h;
+    if (pattern == 0) hipLaunchKernelGGL(k_corr<0>, dim3(v3d_cdiv(waves, 4)), dim3(256), 0, st, fl, frw, C, h, w, G, out);
+    else hipLaunchKernelGGL(k_corr<1>, dim3(v3d_cdiv(waves, 4)), dim3(256), 0, st, fl, frw, C, h, w, G, out);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}

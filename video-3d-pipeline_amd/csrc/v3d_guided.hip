@@ -1,0 +1,169 @@
+// v3d_guided.hip -- guided-filter joint upsampling of the 1080p depth to the 4K guide frame.
+//
+// Stands where reference upscale.py:21-73 (upscale_depth_maps_ffmpeg: ffmpeg `scale` filter)
+// stands; re-specified by BASELINE.json / SURVEY.md 8a-11 + Appendix B.1 as He-Sun-Tang guided
+// filtering:  p = bilinear(depth_lo), I = guide/255,
+//   a = cov(I,p) / (var(I) + eps),  b = mean(p) - a*mean(I),  q = mean(a)*I + mean(b)
+// with (2r+1)^2 box means clipped at the image border and divided by the true pixel count.
+//
+// Two sweeps, each one LDS-tiled kernel (64x16 output tile + r halo), box sums separable with
+// register sliding windows.  HBM traffic: sweep 1 reads guide + depth_lo tiles, writes a,b;
+// sweep 2 reads a,b tiles + guide, writes q.
+#include "v3d_common.h"
+
+#define GF_TX 64
+#define GF_TY 16
+#define GF_RUN 8      // outputs per thread along x in the horizontal pass
+#define GF_RUNY 4     // outputs per thread along y in the vertical pass
+#define GF_RMAX 16
+
+__device__ __forceinline__ float gf_bilinear(const float* __restrict__ src, int Ws, int Hs, float sx, float sy, int x, int y)
+{
+    const float fx = (x + 0.5f) * sx - 0.5f, fy = (y + 0.5f) * sy - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int xa = min(max(x0, 0), Ws - 1), xb = min(max(x0 + 1, 0), Ws - 1);
+    const int ya = min(max(y0, 0), Hs - 1), yb = min(max(y0 + 1, 0), Hs - 1);
+    const float top = src[(size_t)ya * Ws + xa] * (1.f - wx) + src[(size_t)ya * Ws + xb] * wx;
+    const float bot = src[(size_t)yb * Ws + xa] * (1.f - wx) + src[(size_t)yb * Ws + xb] * wx;
+    return top * (1.f - wy) + bot * wy;
+}
+
+// NQ_IN planes staged (2), NQ_SUM planes summed (4 in sweep 1: I, p, II, Ip; 2 in sweep 2: a, b)
+template <int SWEEP>
+__global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+                                            const uint8_t* __restrict__ guide, int W, int H, int r, float eps,
+                                            float* __restrict__ A, float* __restrict__ B, float* __restrict__ out)
+{
+    constexpr int NS = SWEEP == 1 ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int rows = GF_TY + 2 * r;                 // staged rows
+    const int pitch = (GF_TX + 2 * r) | 1;          // odd pitch: row-adjacent threads hit different banks
+    const int hp = GF_TX + 1;                       // pitch of the horizontal-sum planes
+    float* t0 = smem;                               // I  (sweep 1) / a (sweep 2)
+    float* t1 = t0 + rows * pitch;                  // p  (sweep 1) / b (sweep 2)
+    float* hs = t1 + rows * pitch;                  // [NS][rows][hp]
+
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * GF_TX, oy = blockIdx.y * GF_TY;
+    const float sx = (float)Wlo / (float)W, sy = (float)Hlo / (float)H;
+
+    // ---- stage the halo tile; out-of-image entries contribute zero ----
+    const int tw = GF_TX + 2 * r;
+    for (int i = tid; i < rows * tw; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int gx = ox - r + tx, gy = oy - r + ty;
+        float v0 = 0.f, v1 = 0.f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            if (SWEEP == 1) {
+                v0 = (float)guide[(size_t)gy * W + gx] * (1.0f / 255.0f);
+                v1 = gf_bilinear(depth_lo, Wlo, Hlo, sx, sy, gx, gy);
+            } else {
+                v0 = A[(size_t)gy * W + gx];
+                v1 = B[(size_t)gy * W + gx];
+            }
+        }
+        t0[ty * pitch + tx] = v0;
+        t1[ty * pitch + tx] = v1;
+    }
+    __syncthreads();
+
+    // ---- horizontal sliding sums: task = (row, run of GF_RUN outputs) ----
+    const int nruns = GF_TX / GF_RUN;
+    for (int task = tid; task < rows * nruns; task += 256) {
+        const int row = task % rows, run = task / rows;
+        const float* r0 = t0 + row * pitch + run * GF_RUN;
+        const float* r1 = t1 + row * pitch + run * GF_RUN;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int k = 0; k <= 2 * r; k++) {
+            const float u = r0[k], v = r1[k];
+            s0 += u; s1 += v;
+            if (SWEEP == 1) { s2 += u * u; s3 += u * v; }
+        }
+        float* h = hs + row * hp + run * GF_RUN;
+        const int hplane = rows * hp;
+        for (int j = 0; j < GF_RUN; j++) {
+            h[j] = s0; h[hplane + j] = s1;
+            if (SWEEP == 1) { h[2 * hplane + j] = s2; h[3 * hplane + j] = s3; }
+            if (j + 1 < GF_RUN) {
+                const float un = r0[j + 2 * r + 1], vn = r1[j + 2 * r + 1];   // column entering the window
+                const float uo = r0[j], vo = r1[j];                           // column leaving it
+                s0 += un - uo; s1 += vn - vo;
+                if (SWEEP == 1) { s2 += un * un - uo * uo; s3 += un * vn - uo * vo; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical sliding sums + the per-pixel algebra: task = (x, run of GF_RUNY outputs) ----
+    {
+        const int x = tid % GF_TX, runy = tid / GF_TX;                    // 64 x 4 tasks
+        const int hplane = rows * hp;
+        const float* h = hs + (runy * GF_RUNY) * hp + x;
+        float s[NS];
+#pragma unroll
+        for (int q = 0; q < NS; q++) s[q] = 0.f;
+        for (int k = 0; k <= 2 * r; k++)
+#pragma unroll
+            for (int q = 0; q < NS; q++) s[q] += h[q * hplane + k * hp];
+        const int gx = ox + x;
+        const int cx = min(gx + r, W - 1) - max(gx - r, 0) + 1;
+        for (int j = 0; j < GF_RUNY; j++) {
+            const int gy = oy + runy * GF_RUNY + j;
+            if (gx < W && gy < H) {
+                const int cy = min(gy + r, H - 1) - max(gy - r, 0) + 1;
+                const float inv = 1.0f / (float)(cx * cy);
+                if (SWEEP == 1) {
+                    const float mI = s[0] * inv, mp = s[1] * inv, mII = s[2] * inv, mIp = s[3] * inv;
+                    const float var = mII - mI * mI, cov = mIp - mI * mp;
+                    const float a = cov / (var + eps);
+                    A[(size_t)gy * W + gx] = a;
+                    B[(size_t)gy * W + gx] = mp - a * mI;
+                } else {
+                    const float I = (float)guide[(size_t)gy * W + gx] * (1.0f / 255.0f);
+                    out[(size_t)gy * W + gx] = (s[0] * inv) * I + (s[1] * inv);
+                }
+            }
+            if (j + 1 < GF_RUNY) {
+                const int kn = j + 2 * r + 1;
+#pragma unroll
+                for (int q = 0; q < NS; q++) s[q] += h[q * hplane + kn * hp] - h[q * hplane + j * hp];
+            }
+        }
+    }
+}
+
+extern "C" size_t v3d_guided_upscale_ws_bytes(int W, int H)
+{
+    if (W < 1 || H < 1) return 0;
+    return (size_t)W * H * sizeof(float) * 2;
+}
+
+static size_t gf_smem(int r, int ns)
+{
+    const int rows = GF_TY + 2 * r;
+    const int pitch = (GF_TX + 2 * r) | 1;
+    return sizeof(float) * ((size_t)2 * rows * pitch + (size_t)ns * rows * (GF_TX + 1));
+}
+
+extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H,
+                                  int r, float eps, float* out, void* ws, void* stream)
+{
+    if (!depth_lo || !guide || !out || !ws) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (Wlo < 1 || Hlo < 1 || W < 1 || H < 1) { v3d_set_error("bad geometry"); return V3D_ERR_ARG; }
+    if (r < 1 || r > GF_RMAX) { v3d_set_error("radius %d outside [1, %d]", r, GF_RMAX); return V3D_ERR_UNSUPPORTED; }
+    if (!(eps >= 0.f)) { v3d_set_error("eps must be >= 0"); return V3D_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    float* A = reinterpret_cast<float*>(ws);
+    float* B = A + (size_t)W * H;
+    const dim3 grid(v3d_cdiv(W, GF_TX), v3d_cdiv(H, GF_TY));
+    if (gf_smem(r, 4) > 48 * 1024) {     // above the default dynamic-LDS limit: opt in (160 KiB per CU on gfx950)
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_smem(r, 4)));
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_smem(r, 2)));
+    }
+    hipLaunchKernelGGL(k_gf<1>, grid, dim3(256), gf_smem(r, 4), st, depth_lo, Wlo, Hlo, guide, W, H, r, eps, A, B, out);
+    hipLaunchKernelGGL(k_gf<2>, grid, dim3(256), gf_smem(r, 2), st, depth_lo, Wlo, Hlo, guide, W, H, r, eps, A, B, out);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}

@@ -1,0 +1,166 @@
+// v3d_pre.hip -- the per-frame steps either side of the matcher:
+//   depth.py:250-268 split_sbs_frame (cv2.resize INTER_LANCZOS4 horizontal x2 "unsqueeze"),
+//   depth.py:274-275 + 337-338 cvtColor (BGR->RGB->GRAY), depth.py:341/374 (/16, clamp),
+//   depth.py:397-406 save_depth_map (min-max -> uint16).
+// All pure streaming kernels: one read of the input, one write of the output.
+#include "v3d_common.h"
+#include <math.h>
+
+struct LanczosTaps { short t[2][8]; };   // [0]: even output columns (fx = 0.75), [1]: odd (fx = 0.25)
+
+// host: the 8 int16 taps cv::resize builds for fractional offset fx (coefficients scaled by 2^11,
+// rounded half-to-even like cvRound)
+static void lanczos4_taps_host(float x, short* taps)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = { {1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45} };
+    const double PI = 3.1415926535897932384626433832795;
+    float c[8], sum = 0.f;
+    const double y0 = -(x + 3) * PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const float yi = (x + 3 - i);
+        if (fabsf(yi) >= 1e-6f) { const double y = -yi * PI * 0.25; c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y)); }
+        else c[i] = 1e30f;
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) {
+        long r = lrintf(c[i] * sum * 2048.f);
+        taps[i] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+    }
+}
+
+__device__ __forceinline__ int gray_of(int b, int g, int r) { return (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15; }
+
+// one thread = one output pixel of one eye.  GRAY: write luma only; else write the BGR triple.
+template <bool GRAY>
+__global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ sbs, int W, int H, int pitch, int unsqueeze,
+                                                   LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR)
+{
+    const int hw = W >> 1, ow = unsqueeze ? W : hw;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, eye = blockIdx.z;
+    if (x >= ow) return;
+    const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;
+    int b, g, r;
+    if (unsqueeze) {
+        // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x: sx = x/2 - 1, frac 0.75; odd x: sx = (x-1)/2, frac 0.25
+        const int odd = x & 1, sx = odd ? (x >> 1) : (x >> 1) - 1;
+        int ab = 0, ag = 0, ar = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int xs = min(max(sx + k - 3, 0), hw - 1);
+            const int t = taps.t[odd][k];
+            ab += row[xs * 3] * t; ag += row[xs * 3 + 1] * t; ar += row[xs * 3 + 2] * t;
+        }
+        // vertical pass is the identity tap (2048); final descale by 2^22 with rounding, saturate to u8
+        b = min(max((int)(((long long)ab * 2048 + (1 << 21)) >> 22), 0), 255);
+        g = min(max((int)(((long long)ag * 2048 + (1 << 21)) >> 22), 0), 255);
+        r = min(max((int)(((long long)ar * 2048 + (1 << 21)) >> 22), 0), 255);
+    } else {
+        b = row[x * 3]; g = row[x * 3 + 1]; r = row[x * 3 + 2];
+    }
+    uint8_t* out = eye ? outR : outL;
+    if (GRAY) out[(size_t)y * ow + x] = (uint8_t)gray_of(b, g, r);
+    else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
+}
+
+static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, bool gray, hipStream_t st)
+{
+    if (!sbs || !L || !R) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (W % 2 != 0) { v3d_set_error("SBS frame width must be even"); return V3D_ERR_ARG; }
+    if (W < 2 || H < 1 || pitch < W * 3) { v3d_set_error("bad SBS geometry %dx%d pitch %d", W, H, pitch); return V3D_ERR_ARG; }
+    LanczosTaps taps;
+    lanczos4_taps_host(0.75f, taps.t[0]);
+    lanczos4_taps_host(0.25f, taps.t[1]);
+    const int ow = unsqueeze ? W : W / 2;
+    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), H, 2), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R);
+    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), H, 2), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}
+
+extern "C" int v3d_sbs_to_gray(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, void* stream)
+{
+    return split_common(sbs, W, H, pitch, unsqueeze, L, R, true, (hipStream_t)stream);
+}
+extern "C" int v3d_split_sbs(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, void* stream)
+{
+    return split_common(sbs, W, H, pitch, unsqueeze, L, R, false, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void k_bgr_to_gray(const uint8_t* __restrict__ bgr, size_t n, uint8_t* __restrict__ gray)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        gray[i] = (uint8_t)gray_of(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2]);
+}
+extern "C" int v3d_bgr_to_gray(const uint8_t* bgr, size_t n, uint8_t* gray, void* stream)
+{
+    if (!bgr || !gray) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (n == 0) return V3D_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_bgr_to_gray, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bgr, n, gray);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}
+
+__global__ __launch_bounds__(256) void k_disp_to_depth(const int16_t* __restrict__ d, size_t n, float* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float f = (float)d[i] / 16.0f;
+        out[i] = f <= 0.f ? 0.f : f;
+    }
+}
+extern "C" int v3d_disp_to_depth(const int16_t* disp16, size_t n, float* out, void* stream)
+{
+    if (!disp16 || !out) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (n == 0) return V3D_OK;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_disp_to_depth, dim3(blocks), dim3(256), 0, (hipStream_t)stream, disp16, n, out);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}
+
+// ---- save_depth_map normalisation: ((d - min) / (max - min) * 65535).astype(uint16) in float32 ----
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ void k_minmax_init(unsigned* mm) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
+__global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ d, size_t n, unsigned* mm)
+{
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned o = f2ord(d[i]);
+        lo = min(lo, o); hi = max(hi, o);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, s)); hi = max(hi, (unsigned)__shfl_xor((int)hi, s)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+}
+__global__ __launch_bounds__(256) void k_norm_u16(const float* __restrict__ d, size_t n, const unsigned* __restrict__ mm, uint16_t* __restrict__ out)
+{
+    const float mn = ord2f(mm[0]), mx = ord2f(mm[1]);
+    const bool flat = !(mx > mn);
+    const float range = mx - mn;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        if (!flat) {
+            v = __fsub_rn(d[i], mn);
+            v = __fdiv_rn(v, range);
+            v = __fmul_rn(v, 65535.0f);
+        }
+        out[i] = (uint16_t)v;
+    }
+}
+extern "C" int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, float* ws, void* stream)
+{
+    if (!depth || !out || !ws) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (n == 0) return V3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* mm = reinterpret_cast<unsigned*>(ws);
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, mm);
+    hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, st, depth, n, mm);
+    hipLaunchKernelGGL(k_norm_u16, dim3(blocks), dim3(256), 0, st, depth, n, mm, out);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}

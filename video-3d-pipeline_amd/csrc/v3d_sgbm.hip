@@ -1,0 +1,693 @@
+// v3d_sgbm.hip -- semi-global block matching for gfx950 (MI355X), D = 64, blockSize = 5.
+//
+// Replaces cv2.StereoSGBM_create(...).compute(left_gray, right_gray) as invoked at
+// reference depth.py:315-325, 341 (OpenCV MODE_SGBM 5-path default, MODE_HH 8-path optional).
+// Stage map: a-4 k_prefilter + k_cost, a-5 k_chain<...> (one launch per path
+// direction), a-6 the WTA tail of the last k_chain, a-7 k_lrcheck, a-8 k_median3x3 + k_ccl_*.
+//
+// HBM layout (per frame, W1 = W - 64):
+//   rec1, rec2 : uint2 [H][W]        pre-filter records {grad, grad_lo, grad_hi, raw | raw_lo, raw_hi}
+//   C, S       : int16 [H][W1][64]   d fastest: one pixel = one 128-B line
+//   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
+#include "v3d_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pf_grad(const uint8_t* r0, const uint8_t* ru, const uint8_t* rd, int x, int W, int ft)
+{
+    if (x <= 0 || x >= W - 1) return ft;     // tab[0]
+    int g = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + ((int)ru[x + 1] - (int)ru[x - 1]) + ((int)rd[x + 1] - (int)rd[x - 1]);
+    return min(max(g, -ft), ft) + ft;
+}
+__device__ __forceinline__ int pf_raw(const uint8_t* r0, int x, int W, int ft)
+{
+    return (x <= 0 || x >= W - 1) ? ft : (int)r0[x];
+}
+
+__global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2,
+                                                   int W, int H, int pitch, size_t frame_stride, int ft,
+                                                   uint2* __restrict__ rec1, uint2* __restrict__ rec2)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    for (int im = 0; im < 2; im++) {
+        const uint8_t* I = (im ? img2 : img1) + f * frame_stride;
+        const uint8_t* r0 = I + (size_t)y * pitch;
+        const uint8_t* ru = I + (size_t)(y > 0 ? y - 1 : y) * pitch;
+        const uint8_t* rd = I + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
+        const int g = pf_grad(r0, ru, rd, x, W, ft), r = pf_raw(r0, x, W, ft);
+        int gl = g, gr = g, rl = r, rr = r;
+        if (x > 0) { gl = (g + pf_grad(r0, ru, rd, x - 1, W, ft)) >> 1; rl = (r + pf_raw(r0, x - 1, W, ft)) >> 1; }
+        if (x < W - 1) { gr = (g + pf_grad(r0, ru, rd, x + 1, W, ft)) >> 1; rr = (r + pf_raw(r0, x + 1, W, ft)) >> 1; }
+        const int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
+        const int q0 = min(min(rl, rr), r), q1 = max(max(rl, rr), r);
+        uint2 rec;
+        rec.x = (uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24);
+        rec.y = (uint32_t)q0 | ((uint32_t)q1 << 8);
+        (im ? rec2 : rec1)[((size_t)f * H + y) * W + x] = rec;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-4 (ii,iii): BT pixel cost + 5x5 box sum -> C.  One workgroup = a strip of 28 output columns
+// (+2 halo each side) marching down a band of rows; lane = (column, 4 disparities).
+// Per row: BT cost bytes -> LDS row, 5-tap horizontal sum from LDS, 5-row vertical sum in registers.
+// ------------------------------------------------------------------------------------------------
+#define COST_COLS 32
+#define COST_OUT 28
+#define COST_NREC 96
+
+__device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
+{
+    // min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v)) on two disparities at once
+    uint32_t a = pk_max(pk_sub(U, V1), pk_sub(V0, U));
+    uint32_t b = pk_max(pk_sub(V, U1), pk_sub(U0, V));
+    return pk_max(pk_min(a, b), 0u);
+}
+__device__ __forceinline__ uint32_t byte2(uint32_t a, int sa, uint32_t b, int sb)
+{
+    return ((a >> sa) & 0xFFu) | (((b >> sb) & 0xFFu) << 16);
+}
+
+__global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, const uint2* __restrict__ rec2,
+                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C)
+{
+    __shared__ uint2 sR[2][COST_NREC];
+    __shared__ uint2 sL[2][COST_COLS];
+    __shared__ uint32_t sPix[2][COST_COLS][16];
+
+    const int tid = threadIdx.x, col = tid >> 4, dq = tid & 15;
+    const int xr0 = blockIdx.x * COST_OUT;
+    const int ys = blockIdx.y * band_h, ye = min(ys + band_h, H);
+    const int f = blockIdx.z;
+    const uint2* r1 = rec1 + (size_t)f * H * W;
+    const uint2* r2 = rec2 + (size_t)f * H * W;
+    int16_t* Cf = C + (size_t)f * H * W1 * V3D_D;
+
+    const int xrc = min(max(xr0 - 2 + col, 0), W1 - 1);        // clamped cost-region column of this lane
+    const int i0 = xrc - xr0 + 65 - 4 * dq;                    // staged index of the right record for d = 4*dq
+    const bool out_col = (col >= 2) && (col < 2 + COST_OUT) && (xr0 - 2 + col < W1);
+    const int nrows = (ye - ys) + 4;
+
+    // which record this thread stages per row (threads 0..95: right image, 96..127: left image)
+    int ld_x = 0; const uint2* ld_src = nullptr; uint2* ld_dst0 = nullptr; uint2* ld_dst1 = nullptr;
+    if (tid < COST_NREC) {
+        ld_x = min(max(xr0 - 1 + tid, 0), W - 1); ld_src = r2; ld_dst0 = &sR[0][tid]; ld_dst1 = &sR[1][tid];
+    } else if (tid < COST_NREC + COST_COLS) {
+        const int c = tid - COST_NREC;
+        ld_x = min(max(xr0 - 2 + c, 0), W1 - 1) + V3D_D; ld_src = r1; ld_dst0 = &sL[0][c]; ld_dst1 = &sL[1][c];
+    }
+    if (ld_src) *ld_dst0 = ld_src[(size_t)min(max(ys - 2, 0), H - 1) * W + ld_x];
+    __syncthreads();
+
+    uint32_t hE0 = 0, hE1 = 0, hE2 = 0, hE3 = 0, hO0 = 0, hO1 = 0, hO2 = 0, hO3 = 0;
+    const uint32_t P2pk = pk_bcast(P2);
+
+    for (int k = 0; k < nrows; k++) {
+        const int buf = k & 1;
+        uint2 nxt = make_uint2(0, 0);
+        const bool more = (k + 1 < nrows);
+        if (more && ld_src) nxt = ld_src[(size_t)min(max(ys - 2 + k + 1, 0), H - 1) * W + ld_x];
+
+        // ---- BT cost of (xrc, d = 4dq .. 4dq+3) on row clamp(ys - 2 + k) ----
+        const uint2 L = sL[buf][col];
+        const uint2 A = sR[buf][i0], B = sR[buf][i0 - 1], Cc = sR[buf][i0 - 2], Dd = sR[buf][i0 - 3];
+        const uint32_t Ug = pk_bcast(L.x & 0xFF), Ug0 = pk_bcast((L.x >> 8) & 0xFF), Ug1 = pk_bcast((L.x >> 16) & 0xFF);
+        const uint32_t Ur = pk_bcast(L.x >> 24), Ur0 = pk_bcast(L.y & 0xFF), Ur1 = pk_bcast((L.y >> 8) & 0xFF);
+        // pair (d0, d0+1): records A, B ; pair (d0+2, d0+3): records Cc, Dd
+        uint32_t g01 = bt_pair(Ug, Ug0, Ug1, byte2(A.x, 0, B.x, 0), byte2(A.x, 8, B.x, 8), byte2(A.x, 16, B.x, 16));
+        uint32_t r01 = bt_pair(Ur, Ur0, Ur1, byte2(A.x, 24, B.x, 24), byte2(A.y, 0, B.y, 0), byte2(A.y, 8, B.y, 8));
+        uint32_t g23 = bt_pair(Ug, Ug0, Ug1, byte2(Cc.x, 0, Dd.x, 0), byte2(Cc.x, 8, Dd.x, 8), byte2(Cc.x, 16, Dd.x, 16));
+        uint32_t r23 = bt_pair(Ur, Ur0, Ur1, byte2(Cc.x, 24, Dd.x, 24), byte2(Cc.y, 0, Dd.y, 0), byte2(Cc.y, 8, Dd.y, 8));
+        const uint32_t p01 = g01 + pk_shr_u(r01, 2), p23 = g23 + pk_shr_u(r23, 2);      // each half <= 93
+        sPix[buf][col][dq] = (p01 & 0xFFu) | ((p01 >> 16) << 8) | ((p23 & 0xFFu) << 16) | ((p23 >> 16) << 24);
+
+        if (more && ld_src) *(buf ? ld_dst0 : ld_dst1) = nxt;
+        __syncthreads();
+
+        // ---- 5-tap horizontal sum (bytes d0..d3 -> (d0,d2) / (d1,d3) u16 pairs), 5-row vertical sum ----
+        if (out_col) {
+            const uint32_t w0 = sPix[buf][col - 2][dq], w1 = sPix[buf][col - 1][dq], w2 = sPix[buf][col][dq],
+                           w3 = sPix[buf][col + 1][dq], w4 = sPix[buf][col + 2][dq];
+            const uint32_t sa = w0 + w1, sb = w2 + w3;                                   // bytes <= 186: no carry
+            const uint32_t hE = (sa & 0x00FF00FFu) + (sb & 0x00FF00FFu) + (w4 & 0x00FF00FFu);
+            const uint32_t hO = ((sa >> 8) & 0x00FF00FFu) + ((sb >> 8) & 0x00FF00FFu) + ((w4 >> 8) & 0x00FF00FFu);
+            if (k >= 4) {
+                const uint32_t cE = hE + hE0 + hE1 + hE2 + hE3 + P2pk;                   // (d0, d2)
+                const uint32_t cO = hO + hO0 + hO1 + hO2 + hO3 + P2pk;                   // (d1, d3)
+                uint2 o;
+                o.x = (cE & 0xFFFFu) | (cO << 16);
+                o.y = (cE >> 16) | (cO & 0xFFFF0000u);
+                const int y = ys + k - 4;
+                *reinterpret_cast<uint2*>(Cf + ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq) = o;
+            }
+            hE3 = hE2; hE2 = hE1; hE1 = hE0; hE0 = hE;
+            hO3 = hO2; hO2 = hO1; hO1 = hO0; hO0 = hO;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-5 / a-6: one SGM path direction per launch.  A "chain" is one scanline of the direction
+// (a row, a column or a diagonal); a wave runs DPL adjacent chains in lock-step:
+// LPP = 64/DPL lanes per pixel, each lane holding DPL consecutive disparities as DPL/2 packed
+// int16 pairs.  d+-1 neighbours come from v_alignbit + one DPP row shift each way, the min over
+// d from packed mins + a DPP butterfly inside the pixel's lane group: no LDS in the recurrence.
+//   MODE 0: S  = L          (first direction)
+//   MODE 1: S += L (sat)    (middle directions)
+//   MODE 2: S + L -> LDS -> winner-take-all / uniqueness / sub-pixel / right-view keys (last direction)
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const int16_t* C; int16_t* S;
+    int W1, H, W, nframes;
+    int P1, P2;
+    int uniq;                 // uniquenessRatio
+    int16_t* dispw;           // MODE 2: [nframes][H][W]
+    uint32_t* d2key;          // MODE 2: [nframes][H][W]
+};
+
+template <int DPL> struct VecT;
+template <> struct VecT<8> { typedef uint4 type; };
+template <> struct VecT<4> { typedef uint2 type; };
+
+template <int NP> __device__ __forceinline__ void vec_unpack(const uint4& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+template <int NP> __device__ __forceinline__ void vec_unpack(const uint2& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; }
+__device__ __forceinline__ uint4 vec_pack4(const uint32_t (&r)[4]) { return make_uint4(r[0], r[1], r[2], r[3]); }
+__device__ __forceinline__ uint2 vec_pack2(const uint32_t (&r)[2]) { return make_uint2(r[0], r[1]); }
+template <int NP> struct Packer;
+template <> struct Packer<4> { static __device__ __forceinline__ uint4 go(const uint32_t (&r)[4]) { return vec_pack4(r); } };
+template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const uint32_t (&r)[2]) { return vec_pack2(r); } };
+
+// L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta ; returns delta' = min_d L[d] + P2 (both halves)
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t delta, const uint32_t (&c)[NP],
+                                               uint32_t (&L)[NP], uint32_t P1pk, uint32_t P2pk, bool first_lane, bool last_lane)
+{
+    const uint32_t MAXPK = 0x7FFF7FFFu;
+    uint32_t prev = dpp_mov<V3D_DPP_ROW_SHR(1)>(MAXPK, p[NP - 1]);
+    uint32_t next = dpp_mov<V3D_DPP_ROW_SHL(1)>(MAXPK, p[0]);
+    if (LPP < 16) { prev = first_lane ? MAXPK : prev; next = last_lane ? MAXPK : next; }
+    uint32_t m[NP + 1];
+    m[0] = alignbit(p[0], prev, 16);
+#pragma unroll
+    for (int i = 1; i < NP; i++) m[i] = alignbit(p[i], p[i - 1], 16);
+    m[NP] = alignbit(next, p[NP - 1], 16);
+    uint32_t mn = MAXPK;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        uint32_t n = pk_add(pk_min(m[i], m[i + 1]), P1pk);
+        uint32_t t = pk_min(pk_min(p[i], n), delta);
+        L[i] = pk_add(pk_sub(c[i], delta), t);
+        mn = pk_min(mn, L[i]);
+    }
+    mn = pk_min(mn, alignbit(mn, mn, 16));
+    mn = pk_min(mn, dpp_mov<V3D_DPP_QUAD(1, 0, 3, 2)>(mn, mn));
+    mn = pk_min(mn, dpp_mov<V3D_DPP_QUAD(2, 3, 0, 1)>(mn, mn));
+    if (LPP >= 8) mn = pk_min(mn, dpp_mov<V3D_DPP_ROW_HALF_MIRROR>(mn, mn));
+    if (LPP >= 16) mn = pk_min(mn, dpp_mov<V3D_DPP_ROW_MIRROR>(mn, mn));
+    return pk_add(mn, P2pk);
+}
+
+#define WTA_ROWB 144   // bytes per pixel row in LDS (128 + 16 pad, keeps 16-B alignment)
+
+// winner-take-all for one pixel whose 64 aggregated costs sit in LDS (stereosgbm.cpp per-row tail)
+__device__ __forceinline__ void wta_pixel(const unsigned char* srow, bool valid, int x, int y, int frame,
+                                          const ChainArgs& a)
+{
+    uint32_t v[32];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint4 t = *reinterpret_cast<const uint4*>(srow + q * 16);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        kmin = min(kmin, ((v[i] & 0xFFFFu) << 6) | (uint32_t)(2 * i));
+        kmin = min(kmin, ((v[i] >> 16) << 6) | (uint32_t)(2 * i + 1));
+    }
+    const int minS = (int)(kmin >> 6), best = (int)(kmin & 63u);
+    // uniqueness: reject iff exists d, |d-best| > 1, S[d]*(100-uniq) < minS*100  <=>  S[d] < T1
+    const int uq = 100 - a.uniq, thr = minS * 100;
+    int T1 = uq > 0 ? (thr + uq - 1) / uq : (thr > 0 ? 32768 : 0);
+    T1 = min(T1, 32768);
+    const uint32_t T1pk = pk_bcast(T1), one = 0x00010001u;
+    uint32_t cntpk = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) cntpk += pk_minu(pk_subu_sat(T1pk, v[i]), one);
+    const int cnt = (int)(cntpk & 0xFFFFu) + (int)(cntpk >> 16);
+    const unsigned short* s16 = reinterpret_cast<const unsigned short*>(srow);
+    const int sm = best > 0 ? (int)s16[best - 1] : 0, sp = best < V3D_D - 1 ? (int)s16[best + 1] : 0;
+    int cw = (minS < T1) ? 1 : 0;
+    if (best > 0 && sm < T1) cw++;
+    if (best < V3D_D - 1 && sp < T1) cw++;
+    const bool ok = valid && (minS < V3D_MAX_COST) && (cnt <= cw);
+    if (!valid) return;
+    int d16 = V3D_INVALID16;
+    if (ok) {
+        const size_t rowo = ((size_t)frame * a.H + y) * a.W;
+        const int ximg = x + V3D_D;
+        atomicMin(&a.d2key[rowo + ximg - best], ((uint32_t)minS << 6) | (uint32_t)(63 - best));
+        if (best > 0 && best < V3D_D - 1) {
+            const int den = max(sm + sp - 2 * minS, 1);
+            d16 = best * 16 + ((sm - sp) * 16 + den) / (den * 2);
+        } else
+            d16 = best * 16;
+    }
+    a.dispw[((size_t)frame * a.H + y) * a.W + x + V3D_D] = (int16_t)d16;
+}
+
+template <bool HORIZ, int XS, bool YREV, int MODE, int DPL>
+__global__ __launch_bounds__(256) void k_chain(ChainArgs a)
+{
+    constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL;     // chains (pixels) per wave = 64 / LPP
+    constexpr int PF = 4;                                     // prefetch depth (steps)
+    constexpr int BS = 64 / PPW;                              // MODE 2: steps per WTA batch
+    typedef typename VecT<DPL>::type Vec;
+    static_assert(MODE != 2 || HORIZ, "the WTA tail rides on a horizontal direction");
+
+    __shared__ __attribute__((aligned(16))) unsigned char sS[MODE == 2 ? 4 * 64 * WTA_ROWB : 16];
+
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int W1 = a.W1, H = a.H;
+    const int NC = HORIZ ? H : (XS == 0 ? W1 : W1 + H - 1);
+    const int groups = (NC + PPW - 1) / PPW;
+    const int gw = blockIdx.x * 4 + wib;
+    const int frame = gw / groups, grp = gw - frame * groups;
+    if (frame >= a.nframes) return;                           // wave-uniform; no block-wide barriers below
+
+    const int sub = lane / LPP, dl = lane % LPP;
+    const int c0 = grp * PPW, c1 = min(c0 + PPW, NC) - 1;
+    const int c = c0 + sub;
+    const bool cvalid = c <= c1;
+    const int cc = min(c, c1);
+
+    int tlo = 0, thi;
+    if (HORIZ) thi = W1;
+    else if (XS == 0) thi = H;
+    else if (XS > 0) { tlo = max(0, H - 1 - c1); thi = min(H, W1 + H - 1 - c0); }
+    else { tlo = max(0, c0 - (W1 - 1)); thi = min(H, c1 + 1); }
+
+    const int16_t* Cf = a.C + (size_t)frame * H * W1 * V3D_D + dl * DPL;
+    int16_t* Sf = a.S + (size_t)frame * H * W1 * V3D_D + dl * DPL;
+    const int x0 = HORIZ ? 0 : (XS == 0 ? cc : (XS > 0 ? cc - (H - 1) : cc));
+
+    auto pos = [&](int t, int& x, int& y) {
+        if (HORIZ) { x = XS > 0 ? t : W1 - 1 - t; y = cc; }
+        else { y = YREV ? H - 1 - t : t; x = x0 + XS * t; }
+    };
+    auto elem_off = [&](int t) -> int {
+        int x, y; pos(t, x, y);
+        x = min(max(x, 0), W1 - 1);
+        return (y * W1 + x) * V3D_D;
+    };
+
+    const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
+    const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
+
+    uint32_t p[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) p[i] = 0;
+    uint32_t delta = P2pk;                                    // out-of-image predecessor: L = 0, min = 0
+
+    Vec cq[PF], sq[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+        const int o = elem_off(min(tlo + j, thi - 1));
+        cq[j] = *reinterpret_cast<const Vec*>(Cf + o);
+        if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + o);
+    }
+
+    unsigned char* myS = sS + (MODE == 2 ? wib * 64 * WTA_ROWB : 0);
+
+    for (int tb = tlo; tb < thi; tb += (MODE == 2 ? BS : PF)) {
+#pragma unroll
+        for (int jj = 0; jj < (MODE == 2 ? BS : PF); jj++) {
+            const int j = jj % PF;
+            const int t = tb + jj;
+            if (t < thi) {
+                uint32_t cv[NP], sv[NP], L[NP];
+                vec_unpack<NP>(cq[j], cv);
+                if (MODE != 0) vec_unpack<NP>(sq[j], sv);
+                const int o = elem_off(t);
+                {   // refill this queue slot with step t + PF
+                    const int on = elem_off(min(t + PF, thi - 1));
+                    cq[j] = *reinterpret_cast<const Vec*>(Cf + on);
+                    if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + on);
+                }
+                uint32_t nd = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
+                bool active = cvalid;
+                if (!HORIZ && XS != 0) {
+                    int x, y; pos(t, x, y);
+                    active = cvalid && ((unsigned)x < (unsigned)W1);
+#pragma unroll
+                    for (int i = 0; i < NP; i++) L[i] = active ? L[i] : 0u;
+                    nd = active ? nd : P2pk;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; i++) p[i] = L[i];
+                delta = nd;
+                if (MODE == 0) {
+                    if (active) *reinterpret_cast<Vec*>(Sf + o) = Packer<NP>::go(L);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; i++) sv[i] = pk_add_sat(sv[i], L[i]);
+                    if (MODE == 1) {
+                        if (active) *reinterpret_cast<Vec*>(Sf + o) = Packer<NP>::go(sv);
+                    } else {
+                        *reinterpret_cast<Vec*>(myS + (sub * BS + jj) * WTA_ROWB + dl * DPL * 2) = Packer<NP>::go(sv);
+                    }
+                }
+            }
+        }
+        if (MODE == 2) {
+            // lane = (chain, step-in-batch): one pixel per lane, all 64 costs read back from LDS
+            const int wsub = lane / BS, wj = lane % BS;
+            const int t = tb + wj;
+            const int y = c0 + wsub;
+            const int x = XS > 0 ? t : W1 - 1 - t;
+            const bool valid = (y <= c1) && (t < thi);
+            wta_pixel(myS + lane * WTA_ROWB, valid, x, y, frame, a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-7: L-R consistency check; also writes the always-invalid columns x < 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
+                                                 int W, int H, int d12, int16_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t rowo = ((size_t)f * H + y) * W;
+    int d1 = V3D_INVALID16;
+    if (x >= V3D_D) {
+        d1 = dispw[rowo + x];
+        if (d1 != V3D_INVALID16) {
+            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+            const int xa = x - da, xb = x - db;
+            bool bad = true;
+            if (xa >= 0 && xa < W) { const uint32_t k = d2key[rowo + xa]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - da) > d12); } else bad = false;
+            if (xb >= 0 && xb < W) { const uint32_t k = d2key[rowo + xb]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - db) > d12); } else bad = false;
+            if (bad) d1 = V3D_INVALID16;
+        }
+    }
+    out[rowo + x] = (int16_t)d1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-8: medianBlur(3) on int16 with replicated borders (the invalid value takes part like any other).
+// ------------------------------------------------------------------------------------------------
+#define V3D_SORT2(a, b) { const int _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }
+__global__ __launch_bounds__(256) void k_median3x3(const int16_t* __restrict__ src, int W, int H, int16_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const int16_t* s = src + (size_t)f * H * W;
+    const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+    const int16_t* r0 = s + (size_t)max(y - 1, 0) * W;
+    const int16_t* r1 = s + (size_t)y * W;
+    const int16_t* r2 = s + (size_t)min(y + 1, H - 1) * W;
+    int p0 = r0[xm], p1 = r0[x], p2 = r0[xp], p3 = r1[xm], p4 = r1[x], p5 = r1[xp], p6 = r2[xm], p7 = r2[x], p8 = r2[xp];
+    V3D_SORT2(p1, p2); V3D_SORT2(p4, p5); V3D_SORT2(p7, p8); V3D_SORT2(p0, p1);
+    V3D_SORT2(p3, p4); V3D_SORT2(p6, p7); V3D_SORT2(p1, p2); V3D_SORT2(p4, p5);
+    V3D_SORT2(p7, p8); V3D_SORT2(p0, p3); V3D_SORT2(p5, p8); V3D_SORT2(p4, p7);
+    V3D_SORT2(p3, p6); V3D_SORT2(p1, p4); V3D_SORT2(p2, p5); V3D_SORT2(p4, p7);
+    V3D_SORT2(p4, p2); V3D_SORT2(p6, p4); V3D_SORT2(p4, p2);
+    dst[(size_t)f * H * W + (size_t)y * W + x] = (int16_t)p4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a-8: filterSpeckles as connected-component labelling (lock-free union-find).  Components are
+// the 4-connected sets of valid pixels joined where |a - b| <= maxDiff; components of at most
+// maxSpeckleSize pixels are invalidated.  The result does not depend on scheduling: union-find
+// yields the same partition in any order, and sizes are only compared against the threshold.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ccl_ld(const int* L, int i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ccl_find(const int* L, int i)
+{
+    int p = ccl_ld(L, i);
+    while (p != i) { i = p; p = ccl_ld(L, i); }
+    return i;
+}
+__device__ __forceinline__ void ccl_union(int* L, int a, int b)
+{
+    for (;;) {
+        a = ccl_find(L, a); b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang the larger root under the smaller
+        const int old = atomicMin(L + a, b);
+        if (old == a) return;
+        a = old;                                               // somebody re-rooted a meanwhile: retry from there
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ lab, int* __restrict__ size)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t fo = (size_t)blockIdx.z * n;
+    lab[fo + i] = (img[fo + i] != newVal) ? i : -1;
+    size[fo + i] = 0;
+}
+__global__ __launch_bounds__(256) void k_ccl_merge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    const int16_t* im = img + fo; int* L = lab + fo;
+    const int i = y * W + x;
+    const int v = im[i];
+    if (v == newVal) return;
+    if (x + 1 < W) { const int u = im[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) ccl_union(L, i, i + 1); }
+    if (y + 1 < H) { const int u = im[i + W]; if (u != newVal && abs(v - u) <= maxDiff) ccl_union(L, i, i + W); }
+}
+__global__ __launch_bounds__(256) void k_ccl_count(int n, int maxSize, int* __restrict__ lab, int* __restrict__ size)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t fo = (size_t)blockIdx.z * n;
+    int* L = lab + fo;
+    if (L[i] < 0) return;
+    const int r = ccl_find(L, i);
+    L[i] = r;                                                  // path compression (roots keep L[r] == r)
+    // only "<= maxSize or not" matters: stop adding once the root is known to be large
+    if (__hip_atomic_load(size + fo + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(size + fo + r, 1);
+}
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ size)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t fo = (size_t)blockIdx.z * n;
+    const int l = lab[fo + i];
+    if (l < 0) return;
+    // lab[i] was compressed to (an ancestor that was) the root at count time; follow to the root again
+    const int r = ccl_find(lab + fo, i);
+    if (size[fo + r] <= maxSize) img[fo + i] = (int16_t)newVal;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct v3d_sgbm {
+    v3d_sgbm_params prm;
+    int device, maxW, maxH, maxB;
+    int P1, P2, ftzero, uniq, d12;
+    int dpl;                                    // disparities per lane in k_chain (4 or 8)
+    uint2 *rec1, *rec2;
+    int16_t *C, *S, *dispw, *raw, *med;
+    uint32_t* d2key;
+    int32_t* labels;
+    size_t bytes;
+};
+
+extern "C" void v3d_sgbm_default_params(v3d_sgbm_params* p)
+{
+    p->minDisparity = 0; p->numDisparities = 64; p->blockSize = 5; p->P1 = 8 * 3 * 25; p->P2 = 32 * 3 * 25;
+    p->disp12MaxDiff = 1; p->preFilterCap = 0; p->uniquenessRatio = 10; p->speckleWindowSize = 100;
+    p->speckleRange = 32; p->mode = V3D_MODE_SGBM;
+}
+
+template <typename T> static int ws_alloc(T** p, size_t n, size_t* total)
+{
+    const size_t b = ((n * sizeof(T)) + 255) & ~(size_t)255;
+    V3D_HIP_CHECK(hipMalloc((void**)p, b));
+    *total += b;
+    return V3D_OK;
+}
+
+extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW, int maxH, int maxB, v3d_sgbm** out)
+{
+    if (!prm || !out) { v3d_set_error("null argument"); return V3D_ERR_ARG; }
+    if (prm->minDisparity != 0 || prm->numDisparities != V3D_D || prm->blockSize != 5) {
+        v3d_set_error("this build supports minDisparity=0, numDisparities=64, blockSize=5 (got %d, %d, %d)",
+                      prm->minDisparity, prm->numDisparities, prm->blockSize);
+        return V3D_ERR_UNSUPPORTED;
+    }
+    if (prm->mode != V3D_MODE_SGBM && prm->mode != V3D_MODE_HH) { v3d_set_error("unsupported mode %d", prm->mode); return V3D_ERR_UNSUPPORTED; }
+    if (maxW <= V3D_D + 4 || maxH < 1 || maxB < 1) { v3d_set_error("bad geometry %dx%d batch %d", maxW, maxH, maxB); return V3D_ERR_ARG; }
+    if ((size_t)maxW * maxH * V3D_D >= ((size_t)1 << 31)) { v3d_set_error("frame too large for 32-bit volume offsets"); return V3D_ERR_UNSUPPORTED; }
+    V3D_HIP_CHECK(hipSetDevice(device));
+    v3d_sgbm* h = new v3d_sgbm();
+    h->prm = *prm; h->device = device; h->maxW = maxW; h->maxH = maxH; h->maxB = maxB;
+    h->P1 = prm->P1 > 0 ? prm->P1 : 2;
+    h->P2 = prm->P2 > 0 ? prm->P2 : 5; if (h->P2 < h->P1 + 1) h->P2 = h->P1 + 1;
+    h->ftzero = (prm->preFilterCap > 15 ? prm->preFilterCap : 15) | 1;
+    h->uniq = prm->uniquenessRatio >= 0 ? prm->uniquenessRatio : 10;
+    h->d12 = prm->disp12MaxDiff > 0 ? prm->disp12MaxDiff : 1;
+    // int16 headroom of the packed recurrence: L <= C <= P2 + 25*(2*ftzero + 63) and delta = min L + P2
+    // must stay below 32767 (OpenCV forms delta in int32; the reference's P2 = 2400 is far inside)
+    if (2 * h->P2 + 25 * (2 * h->ftzero + 63) >= 32767 || h->ftzero > 31) {   // ftzero <= 31: BT bytes add pairwise without carry in k_cost
+        const int p2 = h->P2; delete h;
+        v3d_set_error("P2=%d / preFilterCap exceed the int16 range of the packed SGM recurrence (need 2*P2 + 25*(2*ftzero+63) < 32767)", p2);
+        return V3D_ERR_UNSUPPORTED;
+    }
+    const char* e = getenv("V3D_CHAIN_DPL");
+    h->dpl = (e && atoi(e) == 4) ? 4 : 8;
+    const size_t px = (size_t)maxW * maxH * maxB, vol = (size_t)(maxW - V3D_D) * maxH * V3D_D * maxB;
+    h->bytes = 0;
+    int rc = 0;
+    rc |= ws_alloc(&h->rec1, px, &h->bytes); rc |= ws_alloc(&h->rec2, px, &h->bytes);
+    rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
+    rc |= ws_alloc(&h->dispw, px, &h->bytes); rc |= ws_alloc(&h->raw, px, &h->bytes); rc |= ws_alloc(&h->med, px, &h->bytes);
+    rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 2, &h->bytes);
+    if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
+    *out = h;
+    return V3D_OK;
+}
+
+extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" size_t v3d_sgbm_workspace_bytes(const v3d_sgbm* h) { return h ? h->bytes : 0; }
+
+template <bool HORIZ, int XS, bool YREV, int MODE>
+static void launch_chain(const v3d_sgbm* h, const ChainArgs& a, hipStream_t st)
+{
+    const int NC = HORIZ ? a.H : (XS == 0 ? a.W1 : a.W1 + a.H - 1);
+    if (h->dpl == 4) {
+        const int groups = v3d_cdiv(NC, 4), waves = groups * a.nframes;
+        hipLaunchKernelGGL((k_chain<HORIZ, XS, YREV, MODE, 4>), dim3(v3d_cdiv(waves, 4)), dim3(256), 0, st, a);
+    } else {
+        const int groups = v3d_cdiv(NC, 8), waves = groups * a.nframes;
+        hipLaunchKernelGGL((k_chain<HORIZ, XS, YREV, MODE, 8>), dim3(v3d_cdiv(waves, 4)), dim3(256), 0, st, a);
+    }
+}
+
+static int check_geometry(const v3d_sgbm* h, int n, int W, int H, int pitch)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    if (n < 1 || n > h->maxB || W > h->maxW || H > h->maxH || (size_t)W * H > (size_t)h->maxW * h->maxH) {
+        v3d_set_error("frame %dx%d x%d exceeds the handle's workspace (%dx%d x%d)", W, H, n, h->maxW, h->maxH, h->maxB);
+        return V3D_ERR_ARG;
+    }
+    if (W <= V3D_D + 4 || H < 1 || pitch < W) { v3d_set_error("bad frame geometry W=%d H=%d pitch=%d (need W > 68)", W, H, pitch); return V3D_ERR_ARG; }
+    return V3D_OK;
+}
+
+// stages: 1 = cost volume, 2 = aggregation + WTA + LR check (raw), 3 = median + speckles (final)
+static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int n, int W, int H, int pitch,
+                    size_t frame_stride, int16_t* out, int last_stage, hipStream_t st)
+{
+    int rc = check_geometry(h, n, W, H, pitch);
+    if (rc) return rc;
+    if (!left || !right || !out) { v3d_set_error("null image pointer"); return V3D_ERR_ARG; }
+    const int W1 = W - V3D_D;
+    const int px = W * H;
+
+    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
+    const int band_h = 136;
+    hipLaunchKernelGGL(k_cost, dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, band_h), n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, band_h, h->P2, h->C);
+    V3D_LAUNCH_CHECK();
+    if (last_stage == 1) return V3D_OK;
+
+    ChainArgs a;
+    a.C = h->C; a.S = h->S; a.W1 = W1; a.H = H; a.W = W; a.nframes = n; a.P1 = h->P1; a.P2 = h->P2; a.uniq = h->uniq;
+    a.dispw = h->dispw; a.d2key = h->d2key;
+    V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
+    // direction order is free (sums commute; saturation of non-negative addends is order-independent)
+    launch_chain<false, 0, false, 0>(h, a, st);         // r2: (x, y-1)
+    launch_chain<false, 1, false, 1>(h, a, st);         // r1: (x-1, y-1)
+    launch_chain<false, -1, false, 1>(h, a, st);        // r3: (x+1, y-1)
+    launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
+    if (h->prm.mode == V3D_MODE_HH) {
+        launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
+        launch_chain<false, -1, true, 1>(h, a, st);     // (x+1, y+1)
+        launch_chain<false, 1, true, 1>(h, a, st);      // (x-1, y+1)
+    }
+    launch_chain<true, -1, false, 2>(h, a, st);         // r4: (x+1, y), + WTA tail
+    V3D_LAUNCH_CHECK();
+    int16_t* raw = (last_stage == 2) ? out : h->raw;
+    hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, raw);
+    V3D_LAUNCH_CHECK();
+    if (last_stage == 2) return V3D_OK;
+
+    hipLaunchKernelGGL(k_median3x3, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, raw, W, H, out);
+    V3D_LAUNCH_CHECK();
+    if (h->prm.speckleWindowSize > 0) {
+        const int newVal = (h->prm.minDisparity - 1) * 16, maxDiff = 16 * h->prm.speckleRange, maxSize = h->prm.speckleWindowSize;
+        int* lab = h->labels; int* size = h->labels + (size_t)px * n;
+        hipLaunchKernelGGL(k_ccl_init, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, out, px, newVal, lab, size);
+        hipLaunchKernelGGL(k_ccl_merge, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, out, W, H, newVal, maxDiff, lab);
+        hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, px, maxSize, lab, size);
+        hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, out, px, newVal, maxSize, lab, size);
+        V3D_LAUNCH_CHECK();
+    }
+    return V3D_OK;
+}
+
+extern "C" int v3d_sgbm_compute(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int W, int H, int pitch, int16_t* out, void* stream)
+{
+    return run_sgbm(h, l, r, 1, W, H, pitch, 0, out, 3, (hipStream_t)stream);
+}
+extern "C" int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int n, int W, int H, int pitch,
+                                      size_t frame_stride, int16_t* out, void* stream)
+{
+    return run_sgbm(h, l, r, n, W, H, pitch, frame_stride, out, 3, (hipStream_t)stream);
+}
+extern "C" int v3d_sgbm_debug_cost_volume(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int W, int H, int pitch, int16_t* C_out, void* stream)
+{
+    int16_t dummy;
+    int rc = run_sgbm(h, l, r, 1, W, H, pitch, 0, &dummy, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    V3D_HIP_CHECK(hipMemcpyAsync(C_out, h->C, (size_t)(W - V3D_D) * H * V3D_D * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return V3D_OK;
+}
+extern "C" int v3d_sgbm_debug_raw(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int W, int H, int pitch, int16_t* out, int16_t* S_out, void* stream)
+{
+    int rc = run_sgbm(h, l, r, 1, W, H, pitch, 0, out, 2, (hipStream_t)stream);
+    if (rc) return rc;
+    // S holds sum of all directions but the last (the last one is only ever formed on-chip)
+    if (S_out) V3D_HIP_CHECK(hipMemcpyAsync(S_out, h->S, (size_t)(W - V3D_D) * H * V3D_D * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return V3D_OK;
+}
+
+extern "C" int v3d_median3x3_i16(const int16_t* src, int W, int H, int16_t* dst, void* stream)
+{
+    if (!src || !dst || W < 1 || H < 1) { v3d_set_error("bad argument"); return V3D_ERR_ARG; }
+    hipLaunchKernelGGL(k_median3x3, dim3(v3d_cdiv(W, 256), H, 1), dim3(256), 0, (hipStream_t)stream, src, W, H, dst);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}
+
+extern "C" int v3d_filter_speckles(int16_t* img, int W, int H, int newVal, int maxSize, int maxDiff, int32_t* ws, void* stream)
+{
+    if (!img || !ws || W < 1 || H < 1) { v3d_set_error("bad argument"); return V3D_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int px = W * H;
+    int* lab = ws; int* size = ws + px;
+    hipLaunchKernelGGL(k_ccl_init, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, img, px, newVal, lab, size);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(v3d_cdiv(W, 256), H, 1), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
+    hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, px, maxSize, lab, size);
+    hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, img, px, newVal, maxSize, lab, size);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}

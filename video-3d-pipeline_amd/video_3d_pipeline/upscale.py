@@ -1,0 +1,177 @@
+"""Depth upscaling to the 4K frame -- MI355X-native host side.
+
+Mirror of reference src/video_3d_pipeline/upscale.py (class / method names, argument meaning, skip-if-
+exists and error behaviour, CLI flags).  The reference shells out to ffmpeg's `scale` filter + H.264
+(upscale.py:47-63) and never looks at the 4K pixels; BASELINE.json re-specifies the step as
+guided-filter joint upsampling with the 4K frame as guide, which is what
+v3d_guided_upscale computes here.  `use_nvenc` is accepted for signature compatibility (NVENC is an
+NVIDIA encoder); H.264 encoding is used only if an ffmpeg binary exists at run time, otherwise the
+4K depth frames are written as 16-bit PNGs and `output_path` becomes a small JSON manifest.
+"""
+import argparse
+import glob
+import json
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from .utils import get_video_info, iter_frames, read_png16, write_png16
+
+GUIDED_RADIUS = 8       # at 4K; the reference specifies nothing
+GUIDED_EPS = 1e-3       # on [0,1]-scaled guide
+
+
+class HipUpscaleBackend:
+    def __init__(self, device: str = "cuda"):
+        import torch
+        from . import _native
+        if not torch.cuda.is_available():
+            raise RuntimeError("CUDA not available but requested")
+        _native.lib()
+        self.torch, self.native, self.device = torch, _native, torch.device(device)
+
+    def to_luma(self, frame_bgr):
+        d = frame_bgr if self.torch.is_tensor(frame_bgr) else self.native.to_device(frame_bgr, self.device)
+        return d if d.dim() == 2 else self.native.bgr_to_gray(d.contiguous())
+
+    def upscale(self, depth_lo, guide, r, eps):
+        nat = self.native
+        d = depth_lo if self.torch.is_tensor(depth_lo) else nat.to_device(np.asarray(depth_lo, np.float32), self.device)
+        g = self.to_luma(guide)
+        return nat.guided_upscale(d.contiguous(), g.contiguous(), r, eps)
+
+
+class SimpleDepthUpscaler:
+    """ Depth upscaling to the 4K frame (guided filter on the GPU) """
+
+    def __init__(self, use_nvenc: bool = True, radius: int = GUIDED_RADIUS, eps: float = GUIDED_EPS,
+                 device: str = "cuda", backend=None):
+        self.use_nvenc = use_nvenc
+        self.radius, self.eps = radius, eps
+        self.backend = backend if backend is not None else HipUpscaleBackend(device)
+        print(f"Initializing Simple Depth Upscaler...")
+        print(f"NVENC encoding: {self.use_nvenc}")
+
+    def upscale_frame(self, depth_lo: np.ndarray, guide_4k: np.ndarray) -> np.ndarray:
+        """NumPy surface: HxW float32 depth + 2Hx2W(x3) uint8 guide (BGR or luma) -> 2Hx2W float32"""
+        return self.backend.upscale(depth_lo, guide_4k, self.radius, self.eps).cpu().numpy()
+
+    def upscale_depth_maps_ffmpeg(self, depth_dir: str, target_width: int, target_height: int,
+                                  output_path: str, fps: float = 23.976, video_4k_path: str = None):
+        """ Upscale the depth_%06d.png sequence to target_width x target_height (name kept from the reference) """
+        from . import sharding
+
+        print(f"Processing depth upscaling...")
+        print(f"Input: {depth_dir}")
+        print(f"Output: {output_path}")
+        print(f"Target: {target_width}x{target_height} @ {fps}fps")
+
+        depth_files = sorted(glob.glob(os.path.join(depth_dir, "depth_*.png")))
+        if not depth_files:
+            raise ValueError(f"No depth maps found in {depth_dir}")
+        print(f"Found {len(depth_files)} depth maps")
+
+        rank, world = sharding.rank_world()
+        frames_dir = Path(str(Path(output_path).with_suffix("")) + "_frames")
+        frames_dir.mkdir(parents=True, exist_ok=True)
+        torch = self.backend.torch
+        guides = iter_frames(video_4k_path, 0, len(depth_files)) if (video_4k_path and rank == 0) else None
+        n = len(depth_files)
+        for base in range(0, n, world):
+            # rank 0 decodes one round of guide frames and broadcasts it; rank r keeps frame base + r
+            round_frames = None
+            if rank == 0:
+                round_frames = []
+                for _ in range(world):
+                    f = next(guides, None) if guides is not None else None
+                    round_frames.append(None if f is None else self.backend.to_luma(f).cpu().numpy())
+            i = base + rank
+            guide = sharding.broadcast_guide_round(round_frames, (target_height, target_width), self.backend.device) \
+                if video_4k_path else None
+            if i >= n:
+                continue
+            d16 = read_png16(depth_files[i]).astype(np.float32)
+            if guide is None:     # no 4K frame for this index: guide with a flat image == plain smoothing upsample
+                guide = torch.full((target_height, target_width), 128, dtype=torch.uint8, device=self.backend.device)
+            q = self.backend.upscale(d16, guide, self.radius, self.eps)
+            q16 = torch.clamp(torch.round(q), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
+            write_png16(frames_dir / f"depth4k_{i:06d}.png", q16)
+        sharding.barrier()
+
+        if rank == 0:
+            ffmpeg = shutil.which("ffmpeg")
+            if ffmpeg and str(output_path).endswith(".mp4"):
+                cmd = [ffmpeg, "-y", "-v", "error", "-r", str(fps), "-f", "image2", "-i", str(frames_dir / "depth4k_%06d.png"),
+                       "-vcodec", "libx264", "-pix_fmt", "yuv420p", "-crf", "18", "-preset", "medium", "-r", str(fps), str(output_path)]
+                res = subprocess.run(cmd, capture_output=True)
+                if res.returncode != 0:
+                    print("FFmpeg error:")
+                    print(res.stderr.decode())
+                    raise RuntimeError(f"FFmpeg processing failed: rc={res.returncode}")
+            else:
+                Path(output_path).write_text(json.dumps({
+                    "format": "png16-sequence", "frames_dir": str(frames_dir), "pattern": "depth4k_%06d.png",
+                    "count": n, "width": target_width, "height": target_height, "fps": fps,
+                    "guided_radius": self.radius, "guided_eps": self.eps,
+                    "note": "no ffmpeg binary on this host: 4K depth frames kept as 16-bit PNGs"}, indent=1))
+        sharding.barrier()
+        print(f"✓ Depth video saved: {output_path}")
+        return output_path
+
+    def process_depth_upscaling(self, depth_dir: str, video_4k_path: str, output_path: str = None,
+                                force_reprocess: bool = False) -> str:
+        """ Main pipeline for depth upscaling """
+        print(f"Processing depth upscaling...")
+        print(f"Depth maps: {depth_dir}")
+        print(f"4K video: {video_4k_path}")
+
+        video_info = get_video_info(video_4k_path)
+        if not video_info:
+            raise ValueError(f"Could not read video info: {video_4k_path}")
+        target_width, target_height, fps = video_info['width'], video_info['height'], video_info['fps']
+        print(f"Target resolution: {target_width}x{target_height} @ {fps}fps")
+
+        if output_path is None:
+            depth_dir_name = Path(depth_dir).name
+            output_path = f"depth_4k_{depth_dir_name}.mp4"
+        output_path = Path(output_path)
+
+        if output_path.exists() and not force_reprocess:
+            print(f"✓ Using existing depth video: {output_path}")
+            return str(output_path)
+
+        result = self.upscale_depth_maps_ffmpeg(depth_dir=depth_dir, target_width=target_width, target_height=target_height,
+                                                output_path=str(output_path), fps=fps, video_4k_path=video_4k_path)
+        print(f"✓ Depth upscaling complete!")
+        print(f"  Input: {depth_dir}")
+        print(f"  Output: {result}")
+        print(f"  Resolution: {target_width}x{target_height}")
+        return result
+
+
+def main(argv=None):
+    """ Command line interface for depth upscaling """
+    parser = argparse.ArgumentParser(description='Depth upscaling to the 4K frame (guided filter)')
+    parser.add_argument('depth_dir', help='Directory containing depth maps')
+    parser.add_argument('video_4k', help='Path to 4K 2D video (dimensions and guide frames)')
+    parser.add_argument('--output', help='Output path for 4K depth video')
+    parser.add_argument('--no-nvenc', action='store_true', help='Disable NVENC, use CPU encoding')
+    parser.add_argument('--force', action='store_true', help='Force reprocessing even if output exists')
+    args = parser.parse_args(argv)
+    try:
+        upscaler = SimpleDepthUpscaler(use_nvenc=not args.no_nvenc)
+        output_path = upscaler.process_depth_upscaling(depth_dir=args.depth_dir, video_4k_path=args.video_4k,
+                                                       output_path=args.output, force_reprocess=args.force)
+        print(f"\n✓ Success! 4K depth video: {output_path}")
+        print(f"Ready for VisionDepth3D processing!")
+    except Exception as e:
+        print(f"Error: {e}")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    exit(main())

@@ -1,0 +1,182 @@
+"""Shared helpers for the hot path (mirror of the two functions of reference utils.py the path uses:
+get_video_info, utils.py:17-38, and create_work_directory, utils.py:292-296), plus the frame source /
+PNG sink either side of it.
+
+Unlike the reference module this one imports nothing heavy at module top (the reference drags in
+cv2/librosa/soundfile/matplotlib, utils.py:3-14): decoders are probed lazily, in this order:
+ffprobe/ffmpeg binaries, cv2, and -- always available -- the self-describing frame containers used by
+the tests and the bench (`*.npy` / `*.npz` stacks of HxWx3 uint8 BGR frames, or a directory of
+`frame_%06d.png`).
+"""
+import json
+import os
+import shutil
+import subprocess
+from fractions import Fraction
+from pathlib import Path
+from typing import Dict, Iterator, Optional
+
+import numpy as np
+
+
+def create_work_directory(base_path: str = "temp_pipeline") -> Path:
+    """ Create and return working directory path """
+    work_dir = Path(base_path)
+    work_dir.mkdir(exist_ok=True)
+    return work_dir
+
+
+def _parse_rate(s) -> float:
+    # the reference eval()s ffprobe's "24000/1001" (utils.py:32); parse it instead
+    try:
+        return float(Fraction(str(s)))
+    except (ValueError, ZeroDivisionError):
+        return float(s)
+
+
+def _frame_dir_files(path: Path):
+    return sorted(path.glob("frame_*.png"))
+
+
+def _container_kind(video_path: str) -> Optional[str]:
+    p = Path(video_path)
+    if p.is_dir() and _frame_dir_files(p):
+        return "pngdir"
+    if p.suffix == ".npy" and p.exists():
+        return "npy"
+    if p.suffix == ".npz" and p.exists():
+        return "npz"
+    return None
+
+
+def _open_stack(video_path: str):
+    kind = _container_kind(video_path)
+    if kind == "npy":
+        return np.load(video_path, mmap_mode="r"), 23.976
+    if kind == "npz":
+        z = np.load(video_path)
+        return z["frames"], float(z["fps"]) if "fps" in z.files else 23.976
+    raise ValueError(video_path)
+
+
+def get_video_info(video_path: str) -> Optional[Dict]:
+    """ Get basic video information (width, height, fps, duration, frames); None if unreadable """
+    try:
+        kind = _container_kind(video_path)
+        if kind in ("npy", "npz"):
+            frames, fps = _open_stack(video_path)
+            n, h, w = frames.shape[0], frames.shape[1], frames.shape[2]
+            return {"width": int(w), "height": int(h), "fps": fps, "duration": n / fps, "frames": int(n)}
+        if kind == "pngdir":
+            from PIL import Image
+            files = _frame_dir_files(Path(video_path))
+            fps = 23.976
+            meta = Path(video_path) / "info.json"
+            if meta.exists():
+                fps = float(json.loads(meta.read_text()).get("fps", fps))
+            with Image.open(files[0]) as im:
+                w, h = im.size
+            return {"width": w, "height": h, "fps": fps, "duration": len(files) / fps, "frames": len(files)}
+        if not os.path.exists(video_path):
+            raise FileNotFoundError(video_path)
+        ffprobe = shutil.which("ffprobe")
+        if ffprobe:
+            out = subprocess.run([ffprobe, "-v", "error", "-print_format", "json", "-show_streams", video_path],
+                                 capture_output=True, check=True, text=True).stdout
+            streams = json.loads(out).get("streams", [])
+            vs = next((s for s in streams if s.get("codec_type") == "video"), None)
+            if not vs:
+                return None
+            return {"width": int(vs["width"]), "height": int(vs["height"]), "fps": _parse_rate(vs["r_frame_rate"]),
+                    "duration": float(vs["duration"]), "frames": int(vs.get("nb_frames", 0))}
+        try:
+            import cv2  # noqa: WPS433 (optional)
+        except ImportError:
+            raise RuntimeError("no decoder available (ffprobe and cv2 are both missing); "
+                               "use a .npy/.npz frame stack or a frame_%06d.png directory")
+        cap = cv2.VideoCapture(video_path)
+        if not cap.isOpened():
+            return None
+        fps = cap.get(cv2.CAP_PROP_FPS) or 23.976
+        n = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        info = {"width": int(cap.get(cv2.CAP_PROP_FRAME_WIDTH)), "height": int(cap.get(cv2.CAP_PROP_FRAME_HEIGHT)),
+                "fps": fps, "duration": n / fps, "frames": n}
+        cap.release()
+        return info
+    except Exception as e:
+        print(f"Error getting video info: {e}")
+        return None
+
+
+def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int] = None) -> Iterator[np.ndarray]:
+    """Stream HxWx3 uint8 BGR frames (bounded memory; the reference loads the whole clip into a list,
+    depth.py:160-176)."""
+    kind = _container_kind(video_path)
+    if kind in ("npy", "npz"):
+        frames, _ = _open_stack(video_path)
+        end = frames.shape[0] if max_frames is None else min(frames.shape[0], start_frame + max_frames)
+        for i in range(start_frame, end):
+            yield np.ascontiguousarray(frames[i])
+        return
+    if kind == "pngdir":
+        from PIL import Image
+        files = _frame_dir_files(Path(video_path))
+        end = len(files) if max_frames is None else min(len(files), start_frame + max_frames)
+        for f in files[start_frame:end]:
+            with Image.open(f) as im:
+                rgb = np.asarray(im.convert("RGB"))
+            yield np.ascontiguousarray(rgb[..., ::-1])
+        return
+    try:
+        import cv2  # noqa: WPS433 (optional)
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        cap = cv2.VideoCapture(video_path)
+        if not cap.isOpened():
+            raise ValueError(f"Could not open video file: {video_path}")
+        cap.set(cv2.CAP_PROP_POS_FRAMES, start_frame)
+        n = 0
+        while max_frames is None or n < max_frames:
+            ret, frame = cap.read()
+            if not ret:
+                break
+            yield frame
+            n += 1
+        cap.release()
+        return
+    ffmpeg = shutil.which("ffmpeg")
+    info = get_video_info(video_path)
+    if not ffmpeg or not info:
+        raise RuntimeError(f"Frame extraction failed: no decoder for {video_path}")
+    cmd = [ffmpeg, "-v", "error", "-ss", str(start_frame / info["fps"]), "-i", video_path]
+    if max_frames is not None:
+        cmd += ["-frames:v", str(max_frames)]
+    cmd += ["-f", "rawvideo", "-pix_fmt", "bgr24", "pipe:"]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
+    size = info["width"] * info["height"] * 3
+    try:
+        while True:
+            buf = proc.stdout.read(size)
+            if not buf or len(buf) != size:
+                break
+            yield np.frombuffer(buf, np.uint8).reshape(info["height"], info["width"], 3)
+    finally:
+        proc.stdout.close()
+        proc.wait()
+
+
+def write_png16(path, img_u16: np.ndarray) -> None:
+    """16-bit single-channel PNG (what cv2.imwrite produces for a uint16 array, depth.py:406)"""
+    from PIL import Image
+    a = np.ascontiguousarray(img_u16, dtype=np.uint16)
+    Image.fromarray(a).save(str(path), format="PNG", compress_level=1)
+
+
+def read_png16(path) -> np.ndarray:
+    from PIL import Image
+    with Image.open(str(path)) as im:
+        a = np.asarray(im)
+    if a.ndim == 3:
+        a = a[..., 0]
+    return a.astype(np.uint16) if a.dtype != np.uint16 else a
