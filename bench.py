@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path: 1080p SBS frame -> SGBM disparity -> guided-filter
+3840x2160 depth (BASELINE.json metric; workload = configs[2], the configuration the metric is quoted on).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of `--batch` (default 8 = the reference's
+batch_size, depth.py:27) synthetic SBS frames already resident in HBM: v3d_sbs_to_gray ->
+v3d_sgbm_compute_batch -> v3d_disp_to_depth -> v3d_guided_upscale against the 4K guide -> float32 4K depth
+in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the
+only collective is the 4K guide round broadcast from rank 0 (RCCL), double-buffered on a side stream.
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (largest summed duration, HIP events on the
+launch stream); `cpu_baseline` = the CPU oracle (a port of the reference's OpenCV path) on one frame.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+W, H, D = 1920, 1080, 64
+SCALE = 2
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+
+def alg_bytes_per_frame():
+    """SURVEY.md 8(d) algorithmic bytes per frame, split over this build's launches so the shares sum
+    to the survey's 1 291 161 600 B (SGBM) + 190 771 200 B (guided upscale).  V = cost-volume bytes."""
+    P = W * H
+    V = (W - D) * H * D * 2
+    sg = {
+        "prefilter": 2 * P,                       # gray in
+        "cost": V,                                # C write
+        "chain_v2": 2 * V / 3, "chain_d1": 2 * V / 3, "chain_d3": 2 * V / 3,   # K_v: C read + S write, 3 launches
+        "chain_h0": V, "chain_h4_wta": V + 2 * P,                              # K_h: C read + S read, + disp16 out
+        "chain_v2r": 0, "chain_d1r": 0, "chain_d3r": 0, "lrcheck": 0, "median": 0, "speckles": 0,
+    }
+    P4 = P * SCALE * SCALE
+    gf = {"guided_sweep1+2": 2 * P4 + 4 * P + 4 * P4 * 2 * 2 + 4 * P4}          # 190 771 200 B (survey figure)
+    return sg, gf
+
+
+def cpu_baseline(sbs, guide):
+    """the oracle (kind 'port': C restatement of the OpenCV path depth.py drives) on ONE frame of the same
+    workload, single thread; plus real OpenCV if the box happens to have it (it does not in this image)."""
+    from oracle import oracle as O
+    O.lib()
+    t0 = time.perf_counter()
+    gl, gr = O.sbs_to_gray(sbs, True)
+    t1 = time.perf_counter()
+    disp = O.sgbm_compute(gl, gr)
+    t2 = time.perf_counter()
+    depth = O.disp_to_depth(disp)
+    O.guided_upscale(depth, guide, 8, 1e-3)
+    t3 = time.perf_counter()
+    total = t3 - t0
+    out = {"value": 1.0 / total, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "1 frame of the same workload (1920x1080 SBS -> 3840x2160 depth), oracle/liboracle.so, 1 thread",
+           "seconds": {"sbs_to_gray": t1 - t0, "sgbm": t2 - t1, "guided_upscale": t3 - t2}}
+    try:
+        import cv2
+        st = cv2.StereoSGBM_create(minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+                                   uniquenessRatio=10, speckleWindowSize=100, speckleRange=32)
+        t4 = time.perf_counter()
+        ref = st.compute(gl, gr)
+        t5 = time.perf_counter()
+        out["opencv"] = {"version": cv2.__version__, "threads": cv2.getNumThreads(), "sgbm_seconds": t5 - t4,
+                         "oracle_mismatch_px": int((ref != disp).sum())}
+    except ImportError:
+        out["opencv"] = "unavailable on this box: parity and CPU baseline are vs this repo's restatement"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (reference batch_size=8)")
+    ap.add_argument("--guide-exchange", choices=["broadcast", "scatter", "none"], default="broadcast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from video_3d_pipeline import _native as N, sharding, synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        sharding.init_process_group("nccl")
+    N.lib()
+    B = args.batch
+
+    # ---- synthetic inputs (two distinct frames, tiled to the batch), resident in HBM ----
+    base_sbs = [syn.sbs_frame(W, H, 2 * rank + i) for i in range(2)]
+    base_guide = [syn.guide_frame(W, H, 2 * rank + i, SCALE) for i in range(2)]
+    sbs = torch.from_numpy(np.stack([base_sbs[i % 2] for i in range(B)])).to(dev)
+    guide_own = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)
+    Hh, Wh = H * SCALE, W * SCALE
+    # guide rounds: round j holds the guide frames of global frames j*world .. j*world+world-1 (rank r owns slot r)
+    if world > 1 and args.guide_exchange != "none":
+        rounds_src = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)      # [B,Hh,Wh]
+        rounds_src = rounds_src[:, None].expand(B, world, Hh, Wh).contiguous() if rank == 0 else None
+        guide_buf = [torch.empty((B, world, Hh, Wh), dtype=torch.uint8, device=dev) if args.guide_exchange == "broadcast"
+                     else torch.empty((B, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(2)]
+        side = torch.cuda.Stream(device=dev)
+    else:
+        rounds_src, guide_buf, side = None, None, None
+
+    lg = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    rg = torch.empty_like(lg)
+    disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    out4k = torch.empty((B, Hh, Wh), dtype=torch.float32, device=dev)
+    matcher = N.StereoSGBM(W, H, B, device=local)
+
+    def exchange(slot):
+        """enqueue the guide exchange for the NEXT step on the side stream"""
+        if guide_buf is None:
+            return None
+        with torch.cuda.stream(side):
+            if args.guide_exchange == "broadcast":
+                if rank == 0:
+                    guide_buf[slot].copy_(rounds_src)
+                dist.broadcast(guide_buf[slot], src=0)
+            else:
+                chunks = [rounds_src[:, r].contiguous() for r in range(world)] if rank == 0 else None
+                dist.scatter(guide_buf[slot], chunks, src=0)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
+    def my_guides(slot):
+        if guide_buf is None:
+            return guide_own
+        return guide_buf[slot][:, rank] if args.guide_exchange == "broadcast" else guide_buf[slot]
+
+    gf_ev = []
+
+    def step(guides, timed):
+        for i in range(B):
+            l, r = N.sbs_to_gray(sbs[i], True)
+            lg[i], rg[i] = l, r
+        matcher.compute(lg, rg, disp)
+        N.disp_to_depth(disp, depth)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for i in range(B):
+            N.guided_upscale(depth[i], guides[i].contiguous() if not guides[i].is_contiguous() else guides[i], 8, 1e-3, out4k[i])
+        if timed:
+            e1.record()
+            gf_ev.append((e0, e1))
+
+    def run(nsteps, timed):
+        evs = []
+        pending = exchange(0)
+        for s in range(nsteps):
+            slot = s & 1
+            if pending is not None:
+                torch.cuda.current_stream().wait_event(pending)
+            nxt = exchange(1 - slot) if s + 1 < nsteps else None
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+            step(my_guides(slot), timed)
+            pending = nxt
+        if timed:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+        return evs
+
+    run(args.warmup, False)
+    torch.cuda.synchronize()
+    matcher.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = run(args.steps, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
+        calls, stage_ms = matcher.read_profile()
+        sg, gf = alg_bytes_per_frame()
+        kernels = {}
+        for name, total in stage_ms.items():
+            if calls and total > 0:
+                kernels[name] = {"avg_ms": total / calls, "alg_bytes": sg.get(name, 0) * B}
+        gfa = sum(a.elapsed_time(b) for a, b in gf_ev) / max(len(gf_ev), 1)
+        kernels["guided_sweep1+2"] = {"avg_ms": gfa / B, "alg_bytes": gf["guided_sweep1+2"]}    # per frame launch pair
+        dom = max((k for k in kernels if not k.startswith("guided")), key=lambda k: kernels[k]["avg_ms"])
+        dk = kernels[dom]
+        achieved = dk["alg_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9
+        sgbm_ms = sum(v["avg_ms"] for k, v in kernels.items() if not k.startswith("guided"))
+        sgbm_alg = sum(sg.values()) * B
+        res = {
+            "metric": "1080p_sbs_to_4k_depth_frames_per_s",
+            "value": world * B * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16 (SGM) + f32 (guided filter)", "data": "synthetic",
+            "config": {"workload": "configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth",
+                       "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_SGBM (5 paths)",
+                       "guided_radius": 8, "guided_eps": 1e-3, "parallelism": f"frames round-robin over {world} GPU(s)",
+                       "guide_exchange": args.guide_exchange if world > 1 else "local"},
+            "p50_ms_per_frame": statistics.median(step_ms) / B,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"],
+                         "sgbm_all_kernels": {"alg_bytes_per_batch": sgbm_alg, "ms_per_batch": sgbm_ms,
+                                              "achieved": sgbm_alg / (sgbm_ms * 1e-3) / 1e9,
+                                              "frac": sgbm_alg / (sgbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "guided_upscale": {"alg_bytes_per_frame": gf["guided_sweep1+2"], "ms_per_frame": gfa / B,
+                                            "achieved": gf["guided_sweep1+2"] / (gfa / B * 1e-3) / 1e9},
+                         "stage_ms_per_launch": {k: round(v["avg_ms"], 4) for k, v in kernels.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(base_sbs[0], base_guide[0])
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    matcher.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,15 @@ int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t*
                            int n, int W, int H, int pitch, size_t frame_stride,
                            int16_t* disp16_out, void* stream);
 
+/* per-stage HIP-event timing on the caller's stream (what bench.py's `roofline` object reads):
+   v3d_sgbm_profile(h, 1) resets and enables; run compute calls; synchronise the stream;
+   v3d_sgbm_profile_read fills total_ms[stage] (n >= v3d_sgbm_profile_stage_count()) and returns the
+   number of recorded calls.  Only full v3d_sgbm_compute[_batch] calls are recorded. */
+int v3d_sgbm_profile(v3d_sgbm* h, int enable);
+int v3d_sgbm_profile_stage_count(void);
+const char* v3d_sgbm_profile_stage_name(int stage);
+int v3d_sgbm_profile_read(v3d_sgbm* h, double* total_ms, int n);
+
 /* stage exports used by the parity tests (same inputs as v3d_sgbm_compute, one frame) */
 /* cost volume C[y][x-64][d] int16, P2 folded in */
 int v3d_sgbm_debug_cost_volume(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
@@ -85,7 +94,7 @@ int v3d_sgbm_debug_cost_volume(v3d_sgbm* h, const uint8_t* left_gray, const uint
 int v3d_sgbm_debug_raw(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t* right_gray,
                        int W, int H, int pitch, int16_t* disp16_out, int16_t* S_out, void* stream);
 int v3d_median3x3_i16(const int16_t* src, int W, int H, int16_t* dst, void* stream);
-/* labels_ws: device scratch of 2*W*H int32 */
+/* labels_ws: device scratch of 3*W*H int32 */
 int v3d_filter_speckles(int16_t* img, int W, int H, int newVal, int maxSpeckleSize, int maxDiff,
                         int32_t* labels_ws, void* stream);
 

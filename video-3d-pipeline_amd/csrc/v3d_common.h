@@ -17,6 +17,7 @@ void v3d_set_error(const char* fmt, ...);
         hipError_t _e = (expr);                                                          \
         if (_e != hipSuccess) {                                                          \
             v3d_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError();   /* clear the sticky error so the next call starts clean */ \
             return V3D_ERR_HIP;                                                          \
         }                                                                                \
     } while (0)

@@ -9,55 +9,58 @@
 // Two sweeps, each one LDS-tiled kernel (64x16 output tile + r halo), box sums separable with
 // register sliding windows.  HBM traffic: sweep 1 reads guide + depth_lo tiles, writes a,b;
 // sweep 2 reads a,b tiles + guide, writes q.
+// Numerics: all sums, a and b are float64 (gfx950 runs f64 vector math at half the f32 rate and this
+// kernel is LDS-bound): next to zero-depth regions q is ~1e-4 while the window holds values ~40, and the
+// 1e-3 *relative* parity bar cannot be met there with f32 cancellation in cov/var and in box(b).
 #include "v3d_common.h"
 
 #define GF_TX 64
-#define GF_TY 16
 #define GF_RUN 8      // outputs per thread along x in the horizontal pass
-#define GF_RUNY 4     // outputs per thread along y in the vertical pass
 #define GF_RMAX 16
+// tile height TY = 4 * RUNY: 16 rows for r <= 8, 8 rows above (keeps the f64 tile inside the 160 KiB LDS)
 
-__device__ __forceinline__ float gf_bilinear(const float* __restrict__ src, int Ws, int Hs, float sx, float sy, int x, int y)
+__device__ __forceinline__ double gf_bilinear(const float* __restrict__ src, int Ws, int Hs, double sx, double sy, int x, int y)
 {
-    const float fx = (x + 0.5f) * sx - 0.5f, fy = (y + 0.5f) * sy - 0.5f;
-    const float x0f = floorf(fx), y0f = floorf(fy);
-    const float wx = fx - x0f, wy = fy - y0f;
+    const double fx = (x + 0.5) * sx - 0.5, fy = (y + 0.5) * sy - 0.5;
+    const double x0f = floor(fx), y0f = floor(fy);
+    const double wx = fx - x0f, wy = fy - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int xa = min(max(x0, 0), Ws - 1), xb = min(max(x0 + 1, 0), Ws - 1);
     const int ya = min(max(y0, 0), Hs - 1), yb = min(max(y0 + 1, 0), Hs - 1);
-    const float top = src[(size_t)ya * Ws + xa] * (1.f - wx) + src[(size_t)ya * Ws + xb] * wx;
-    const float bot = src[(size_t)yb * Ws + xa] * (1.f - wx) + src[(size_t)yb * Ws + xb] * wx;
-    return top * (1.f - wy) + bot * wy;
+    const double top = (double)src[(size_t)ya * Ws + xa] * (1.0 - wx) + (double)src[(size_t)ya * Ws + xb] * wx;
+    const double bot = (double)src[(size_t)yb * Ws + xa] * (1.0 - wx) + (double)src[(size_t)yb * Ws + xb] * wx;
+    return top * (1.0 - wy) + bot * wy;
 }
 
 // NQ_IN planes staged (2), NQ_SUM planes summed (4 in sweep 1: I, p, II, Ip; 2 in sweep 2: a, b)
-template <int SWEEP>
+template <int SWEEP, int GF_RUNY>
 __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, int Wlo, int Hlo,
-                                            const uint8_t* __restrict__ guide, int W, int H, int r, float eps,
-                                            float* __restrict__ A, float* __restrict__ B, float* __restrict__ out)
+                                            const uint8_t* __restrict__ guide, int W, int H, int r, double eps,
+                                            double* __restrict__ A, double* __restrict__ B, float* __restrict__ out)
 {
     constexpr int NS = SWEEP == 1 ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int GF_TY = 4 * GF_RUNY;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int rows = GF_TY + 2 * r;                 // staged rows
     const int pitch = (GF_TX + 2 * r) | 1;          // odd pitch: row-adjacent threads hit different banks
     const int hp = GF_TX + 1;                       // pitch of the horizontal-sum planes
-    float* t0 = smem;                               // I  (sweep 1) / a (sweep 2)
-    float* t1 = t0 + rows * pitch;                  // p  (sweep 1) / b (sweep 2)
-    float* hs = t1 + rows * pitch;                  // [NS][rows][hp]
+    double* t0 = smem;                              // I  (sweep 1) / a (sweep 2)
+    double* t1 = t0 + rows * pitch;                 // p  (sweep 1) / b (sweep 2)
+    double* hs = t1 + rows * pitch;                 // [NS][rows][hp]
 
     const int tid = threadIdx.x;
     const int ox = blockIdx.x * GF_TX, oy = blockIdx.y * GF_TY;
-    const float sx = (float)Wlo / (float)W, sy = (float)Hlo / (float)H;
+    const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
 
     // ---- stage the halo tile; out-of-image entries contribute zero ----
     const int tw = GF_TX + 2 * r;
     for (int i = tid; i < rows * tw; i += 256) {
         const int ty = i / tw, tx = i - ty * tw;
         const int gx = ox - r + tx, gy = oy - r + ty;
-        float v0 = 0.f, v1 = 0.f;
+        double v0 = 0.0, v1 = 0.0;
         if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
             if (SWEEP == 1) {
-                v0 = (float)guide[(size_t)gy * W + gx] * (1.0f / 255.0f);
+                v0 = (double)guide[(size_t)gy * W + gx] / 255.0;
                 v1 = gf_bilinear(depth_lo, Wlo, Hlo, sx, sy, gx, gy);
             } else {
                 v0 = A[(size_t)gy * W + gx];
@@ -73,22 +76,22 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
     const int nruns = GF_TX / GF_RUN;
     for (int task = tid; task < rows * nruns; task += 256) {
         const int row = task % rows, run = task / rows;
-        const float* r0 = t0 + row * pitch + run * GF_RUN;
-        const float* r1 = t1 + row * pitch + run * GF_RUN;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const double* r0 = t0 + row * pitch + run * GF_RUN;
+        const double* r1 = t1 + row * pitch + run * GF_RUN;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         for (int k = 0; k <= 2 * r; k++) {
-            const float u = r0[k], v = r1[k];
+            const double u = r0[k], v = r1[k];
             s0 += u; s1 += v;
             if (SWEEP == 1) { s2 += u * u; s3 += u * v; }
         }
-        float* h = hs + row * hp + run * GF_RUN;
+        double* h = hs + row * hp + run * GF_RUN;
         const int hplane = rows * hp;
         for (int j = 0; j < GF_RUN; j++) {
             h[j] = s0; h[hplane + j] = s1;
             if (SWEEP == 1) { h[2 * hplane + j] = s2; h[3 * hplane + j] = s3; }
             if (j + 1 < GF_RUN) {
-                const float un = r0[j + 2 * r + 1], vn = r1[j + 2 * r + 1];   // column entering the window
-                const float uo = r0[j], vo = r1[j];                           // column leaving it
+                const double un = r0[j + 2 * r + 1], vn = r1[j + 2 * r + 1];  // column entering the window
+                const double uo = r0[j], vo = r1[j];                          // column leaving it
                 s0 += un - uo; s1 += vn - vo;
                 if (SWEEP == 1) { s2 += un * un - uo * uo; s3 += un * vn - uo * vo; }
             }
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
     {
         const int x = tid % GF_TX, runy = tid / GF_TX;                    // 64 x 4 tasks
         const int hplane = rows * hp;
-        const float* h = hs + (runy * GF_RUNY) * hp + x;
-        float s[NS];
+        const double* h = hs + (runy * GF_RUNY) * hp + x;
+        double s[NS];
 #pragma unroll
-        for (int q = 0; q < NS; q++) s[q] = 0.f;
+        for (int q = 0; q < NS; q++) s[q] = 0.0;
         for (int k = 0; k <= 2 * r; k++)
 #pragma unroll
             for (int q = 0; q < NS; q++) s[q] += h[q * hplane + k * hp];
@@ -113,16 +116,16 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
             const int gy = oy + runy * GF_RUNY + j;
             if (gx < W && gy < H) {
                 const int cy = min(gy + r, H - 1) - max(gy - r, 0) + 1;
-                const float inv = 1.0f / (float)(cx * cy);
+                const double cnt = (double)(cx * cy);
                 if (SWEEP == 1) {
-                    const float mI = s[0] * inv, mp = s[1] * inv, mII = s[2] * inv, mIp = s[3] * inv;
-                    const float var = mII - mI * mI, cov = mIp - mI * mp;
-                    const float a = cov / (var + eps);
+                    const double mI = s[0] / cnt, mp = s[1] / cnt, mII = s[2] / cnt, mIp = s[3] / cnt;
+                    const double var = mII - mI * mI, cov = mIp - mI * mp;
+                    const double a = cov / (var + eps);
                     A[(size_t)gy * W + gx] = a;
                     B[(size_t)gy * W + gx] = mp - a * mI;
                 } else {
-                    const float I = (float)guide[(size_t)gy * W + gx] * (1.0f / 255.0f);
-                    out[(size_t)gy * W + gx] = (s[0] * inv) * I + (s[1] * inv);
+                    const double I = (double)guide[(size_t)gy * W + gx] / 255.0;
+                    out[(size_t)gy * W + gx] = (float)((s[0] / cnt) * I + (s[1] / cnt));
                 }
             }
             if (j + 1 < GF_RUNY) {
@@ -137,14 +140,14 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
 extern "C" size_t v3d_guided_upscale_ws_bytes(int W, int H)
 {
     if (W < 1 || H < 1) return 0;
-    return (size_t)W * H * sizeof(float) * 2;
+    return (size_t)W * H * sizeof(double) * 2;
 }
 
-static size_t gf_smem(int r, int ns)
+static size_t gf_smem(int r, int ns, int ty)
 {
-    const int rows = GF_TY + 2 * r;
+    const int rows = ty + 2 * r;
     const int pitch = (GF_TX + 2 * r) | 1;
-    return sizeof(float) * ((size_t)2 * rows * pitch + (size_t)ns * rows * (GF_TX + 1));
+    return sizeof(double) * ((size_t)2 * rows * pitch + (size_t)ns * rows * (GF_TX + 1));
 }
 
 extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H,
@@ -155,15 +158,23 @@ extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const
     if (r < 1 || r > GF_RMAX) { v3d_set_error("radius %d outside [1, %d]", r, GF_RMAX); return V3D_ERR_UNSUPPORTED; }
     if (!(eps >= 0.f)) { v3d_set_error("eps must be >= 0"); return V3D_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    float* A = reinterpret_cast<float*>(ws);
-    float* B = A + (size_t)W * H;
-    const dim3 grid(v3d_cdiv(W, GF_TX), v3d_cdiv(H, GF_TY));
-    if (gf_smem(r, 4) > 48 * 1024) {     // above the default dynamic-LDS limit: opt in (160 KiB per CU on gfx950)
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_smem(r, 4)));
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gf_smem(r, 2)));
+    double* A = reinterpret_cast<double*>(ws);
+    double* B = A + (size_t)W * H;
+    const int ty = r <= 8 ? 16 : 8;
+    const dim3 grid(v3d_cdiv(W, GF_TX), v3d_cdiv(H, ty));
+    const size_t sm1 = gf_smem(r, 4, ty), sm2 = gf_smem(r, 2, ty);
+    if (ty == 16) {
+        // above the default dynamic-LDS limit: opt in (160 KiB per CU on gfx950)
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
+        hipLaunchKernelGGL((k_gf<1, 4>), grid, dim3(256), sm1, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
+        hipLaunchKernelGGL((k_gf<2, 4>), grid, dim3(256), sm2, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
+    } else {
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
+        hipLaunchKernelGGL((k_gf<1, 2>), grid, dim3(256), sm1, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
+        hipLaunchKernelGGL((k_gf<2, 2>), grid, dim3(256), sm2, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
     }
-    hipLaunchKernelGGL(k_gf<1>, grid, dim3(256), gf_smem(r, 4), st, depth_lo, Wlo, Hlo, guide, W, H, r, eps, A, B, out);
-    hipLaunchKernelGGL(k_gf<2>, grid, dim3(256), gf_smem(r, 2), st, depth_lo, Wlo, Hlo, guide, W, H, r, eps, A, B, out);
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }

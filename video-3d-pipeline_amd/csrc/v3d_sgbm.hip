@@ -10,6 +10,7 @@
 //   C, S       : int16 [H][W1][64]   d fastest: one pixel = one 128-B line
 //   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
 #include "v3d_common.h"
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------
 // a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
@@ -420,10 +421,16 @@ __global__ __launch_bounds__(256) void k_median3x3(const int16_t* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
-// a-8: filterSpeckles as connected-component labelling (lock-free union-find).  Components are
-// the 4-connected sets of valid pixels joined where |a - b| <= maxDiff; components of at most
-// maxSpeckleSize pixels are invalidated.  The result does not depend on scheduling: union-find
-// yields the same partition in any order, and sizes are only compared against the threshold.
+// a-8: filterSpeckles as run-based connected-component labelling.  Components are the 4-connected
+// sets of valid pixels joined where |a - b| <= maxDiff; components of at most maxSpeckleSize pixels
+// are invalidated.  (1) every row is cut into horizontal runs by a block-wide scan (no atomics);
+// a run is named by the index of its first pixel and carries its length.  (2) runs of adjacent
+// rows are joined with a lock-free union-find, one union per overlapping run pair instead of one
+// per pixel.  (3) run lengths are added at the roots, (4) small components are erased.
+// The outcome is schedule-independent: union-find yields the same partition in any order, and
+// sizes are only ever compared against the threshold.
+//   lab  [n]: run start for non-start pixels (constant); parent pointer for run starts; -1 invalid
+//   rlen [n]: run length at run starts, 0 elsewhere;  csz [n]: component size, accumulated at roots
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ccl_ld(const int* L, int i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ccl_find(const int* L, int i)
@@ -440,52 +447,108 @@ __device__ __forceinline__ void ccl_union(int* L, int a, int b)
         if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang the larger root under the smaller
         const int old = atomicMin(L + a, b);
         if (old == a) return;
-        a = old;                                               // somebody re-rooted a meanwhile: retry from there
+        a = old;                                               // a was re-rooted meanwhile: carry on from its old parent
+    }
+}
+__device__ __forceinline__ bool ccl_conn(int a, int b, int newVal, int maxDiff) { return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
+
+// one block per image row
+__global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff,
+                                                  int* __restrict__ lab, int* __restrict__ rlen, int* __restrict__ csz)
+{
+    __shared__ int sLast[256];
+    const int y = blockIdx.x, t = threadIdx.x;
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    const int16_t* row = img + fo + (size_t)y * W;
+    const int ppt = (W + 255) / 256;
+    const int xa = min(t * ppt, W), xb = min(xa + ppt, W);
+    // pass 1: last run start inside my chunk
+    int last = -1;
+    int prev = xa > 0 ? (int)row[xa - 1] : newVal;
+    for (int x = xa; x < xb; x++) {
+        const int v = row[x];
+        if (v != newVal && !ccl_conn(prev, v, newVal, maxDiff)) last = x;
+        prev = v;
+    }
+    sLast[t] = last;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                 // inclusive max-scan
+        const int o = t >= off ? sLast[t - off] : -1;
+        __syncthreads();
+        sLast[t] = max(sLast[t], o);
+        __syncthreads();
+    }
+    int cur = t > 0 ? sLast[t - 1] : -1;                       // run start carried in from the left
+    // pass 2: labels, run lengths
+    prev = xa > 0 ? (int)row[xa - 1] : newVal;
+    for (int x = xa; x < xb; x++) {
+        const int v = row[x];
+        const size_t i = fo + (size_t)y * W + x;
+        csz[i] = 0;
+        if (v == newVal) { lab[i] = -1; rlen[i] = 0; }
+        else {
+            const bool start = !ccl_conn(prev, v, newVal, maxDiff);
+            if (start) cur = x; else rlen[i] = 0;
+            lab[i] = y * W + cur;
+            const int nxt = x + 1 < W ? (int)row[x + 1] : newVal;
+            if (!ccl_conn(v, nxt, newVal, maxDiff)) rlen[fo + (size_t)y * W + cur] = x - cur + 1;   // I am the run's last pixel
+        }
+        prev = v;
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_init(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ lab, int* __restrict__ size)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t fo = (size_t)blockIdx.z * n;
-    lab[fo + i] = (img[fo + i] != newVal) ? i : -1;
-    size[fo + i] = 0;
-}
-__global__ __launch_bounds__(256) void k_ccl_merge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
+__global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+    if (x >= W || y + 1 >= H) return;
     const size_t fo = (size_t)blockIdx.z * W * H;
     const int16_t* im = img + fo; int* L = lab + fo;
     const int i = y * W + x;
-    const int v = im[i];
-    if (v == newVal) return;
-    if (x + 1 < W) { const int u = im[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) ccl_union(L, i, i + 1); }
-    if (y + 1 < H) { const int u = im[i + W]; if (u != newVal && abs(v - u) <= maxDiff) ccl_union(L, i, i + W); }
+    const int v = im[i], u = im[i + W];
+    if (!ccl_conn(v, u, newVal, maxDiff)) return;
+    if (x > 0) {      // the pixel to my left joins the same two runs: it (or one further left) does the union
+        const int vl = im[i - 1], ul = im[i + W - 1];
+        if (ccl_conn(vl, ul, newVal, maxDiff) && ccl_conn(vl, v, newVal, maxDiff) && ccl_conn(ul, u, newVal, maxDiff)) return;
+    }
+    ccl_union(L, L[i], L[i + W]);
 }
-__global__ __launch_bounds__(256) void k_ccl_count(int n, int maxSize, int* __restrict__ lab, int* __restrict__ size)
+
+__global__ __launch_bounds__(256) void k_ccl_count(int n, int maxSize, int* __restrict__ lab, const int* __restrict__ rlen, int* __restrict__ csz)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const size_t fo = (size_t)blockIdx.z * n;
+    const int len = rlen[fo + i];
+    if (len <= 0) return;                                      // run starts only
     int* L = lab + fo;
-    if (L[i] < 0) return;
     const int r = ccl_find(L, i);
-    L[i] = r;                                                  // path compression (roots keep L[r] == r)
+    if (r != i) L[i] = r;                                      // path compression (the forest is final here)
     // only "<= maxSize or not" matters: stop adding once the root is known to be large
-    if (__hip_atomic_load(size + fo + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(size + fo + r, 1);
+    if (__hip_atomic_load(csz + fo + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(csz + fo + r, len);
 }
-__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ size)
+
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ csz)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const size_t fo = (size_t)blockIdx.z * n;
     const int l = lab[fo + i];
     if (l < 0) return;
-    // lab[i] was compressed to (an ancestor that was) the root at count time; follow to the root again
-    const int r = ccl_find(lab + fo, i);
-    if (size[fo + r] <= maxSize) img[fo + i] = (int16_t)newVal;
+    const int r = ccl_find(lab + fo, l);
+    if (csz[fo + r] <= maxSize) img[fo + i] = (int16_t)newVal;
+}
+
+// the four launches; ws = 3 * n_pixels * frames int32
+static int launch_speckles(int16_t* img, int W, int H, int frames, int newVal, int maxSize, int maxDiff, int32_t* ws, hipStream_t st)
+{
+    const int px = W * H;
+    int* lab = ws; int* rlen = ws + (size_t)px * frames; int* csz = ws + (size_t)px * frames * 2;
+    hipLaunchKernelGGL(k_ccl_runs, dim3(H, 1, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab, rlen, csz);
+    hipLaunchKernelGGL(k_ccl_vmerge, dim3(v3d_cdiv(W, 256), H, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
+    hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, px, maxSize, lab, rlen, csz);
+    hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, img, px, newVal, maxSize, lab, csz);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,7 +564,23 @@ struct v3d_sgbm {
     uint32_t* d2key;
     int32_t* labels;
     size_t bytes;
+    // optional per-stage HIP-event timing (v3d_sgbm_profile): events live on the caller's stream
+    bool prof_on;
+    int prof_calls;
+    std::vector<hipEvent_t> prof_ev;            // [call][V3D_NSTAGE + 1]
 };
+
+enum { ST_PREFILTER = 0, ST_COST, ST_V2, ST_D1, ST_D3, ST_H0, ST_V2R, ST_D1R, ST_D3R, ST_H4_WTA, ST_LRCHECK, ST_MEDIAN, ST_SPECKLE, V3D_NSTAGE };
+static const char* const g_stage_names[V3D_NSTAGE] = { "prefilter", "cost", "chain_v2", "chain_d1", "chain_d3", "chain_h0",
+    "chain_v2r", "chain_d1r", "chain_d3r", "chain_h4_wta", "lrcheck", "median", "speckles" };
+#define V3D_PROF_MAX_CALLS 512
+
+// record the event that closes stage `st` (and opens st+1); stages that are skipped record nothing
+static inline void prof_mark(v3d_sgbm* h, int slot, hipStream_t stm)
+{
+    if (!h->prof_on || h->prof_calls >= V3D_PROF_MAX_CALLS) return;
+    (void)hipEventRecord(h->prof_ev[(size_t)h->prof_calls * (V3D_NSTAGE + 1) + slot], stm);
+}
 
 extern "C" void v3d_sgbm_default_params(v3d_sgbm_params* p)
 {
@@ -531,6 +610,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     if ((size_t)maxW * maxH * V3D_D >= ((size_t)1 << 31)) { v3d_set_error("frame too large for 32-bit volume offsets"); return V3D_ERR_UNSUPPORTED; }
     V3D_HIP_CHECK(hipSetDevice(device));
     v3d_sgbm* h = new v3d_sgbm();
+    h->prof_on = false; h->prof_calls = 0;
     h->prm = *prm; h->device = device; h->maxW = maxW; h->maxH = maxH; h->maxB = maxB;
     h->P1 = prm->P1 > 0 ? prm->P1 : 2;
     h->P2 = prm->P2 > 0 ? prm->P2 : 5; if (h->P2 < h->P1 + 1) h->P2 = h->P1 + 1;
@@ -552,7 +632,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     rc |= ws_alloc(&h->rec1, px, &h->bytes); rc |= ws_alloc(&h->rec2, px, &h->bytes);
     rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
     rc |= ws_alloc(&h->dispw, px, &h->bytes); rc |= ws_alloc(&h->raw, px, &h->bytes); rc |= ws_alloc(&h->med, px, &h->bytes);
-    rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 2, &h->bytes);
+    rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
     return V3D_OK;
@@ -564,6 +644,7 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
     (void)hipSetDevice(h->device);
     void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -603,10 +684,13 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     const int W1 = W - V3D_D;
     const int px = W * H;
 
+    prof_mark(h, ST_PREFILTER, st);
     hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
+    prof_mark(h, ST_COST, st);
     const int band_h = 136;
     hipLaunchKernelGGL(k_cost, dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, band_h), n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, band_h, h->P2, h->C);
     V3D_LAUNCH_CHECK();
+    prof_mark(h, ST_V2, st);
     if (last_stage == 1) return V3D_OK;
 
     ChainArgs a;
@@ -615,33 +699,72 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
     launch_chain<false, 0, false, 0>(h, a, st);         // r2: (x, y-1)
+    prof_mark(h, ST_D1, st);
     launch_chain<false, 1, false, 1>(h, a, st);         // r1: (x-1, y-1)
+    prof_mark(h, ST_D3, st);
     launch_chain<false, -1, false, 1>(h, a, st);        // r3: (x+1, y-1)
+    prof_mark(h, ST_H0, st);
     launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
+    prof_mark(h, ST_V2R, st);
     if (h->prm.mode == V3D_MODE_HH) {
         launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
+        prof_mark(h, ST_D1R, st);
         launch_chain<false, -1, true, 1>(h, a, st);     // (x+1, y+1)
+        prof_mark(h, ST_D3R, st);
         launch_chain<false, 1, true, 1>(h, a, st);      // (x-1, y+1)
-    }
+    } else { prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st); }
+    prof_mark(h, ST_H4_WTA, st);
     launch_chain<true, -1, false, 2>(h, a, st);         // r4: (x+1, y), + WTA tail
     V3D_LAUNCH_CHECK();
+    prof_mark(h, ST_LRCHECK, st);
     int16_t* raw = (last_stage == 2) ? out : h->raw;
     hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, raw);
     V3D_LAUNCH_CHECK();
+    prof_mark(h, ST_MEDIAN, st);
     if (last_stage == 2) return V3D_OK;
 
     hipLaunchKernelGGL(k_median3x3, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, raw, W, H, out);
     V3D_LAUNCH_CHECK();
+    prof_mark(h, ST_SPECKLE, st);
     if (h->prm.speckleWindowSize > 0) {
         const int newVal = (h->prm.minDisparity - 1) * 16, maxDiff = 16 * h->prm.speckleRange, maxSize = h->prm.speckleWindowSize;
-        int* lab = h->labels; int* size = h->labels + (size_t)px * n;
-        hipLaunchKernelGGL(k_ccl_init, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, out, px, newVal, lab, size);
-        hipLaunchKernelGGL(k_ccl_merge, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, out, W, H, newVal, maxDiff, lab);
-        hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, px, maxSize, lab, size);
-        hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, n), dim3(256), 0, st, out, px, newVal, maxSize, lab, size);
-        V3D_LAUNCH_CHECK();
+        rc = launch_speckles(out, W, H, n, newVal, maxSize, maxDiff, h->labels, st);
+        if (rc) return rc;
     }
+    prof_mark(h, V3D_NSTAGE, st);
+    if (h->prof_on && h->prof_calls < V3D_PROF_MAX_CALLS) h->prof_calls++;
     return V3D_OK;
+}
+
+// ---- per-stage timing: enable (resets the counters), run any number of compute calls, synchronise the
+// stream, then read.  Events are recorded on the caller's stream between the stage launches. ----
+extern "C" int v3d_sgbm_profile(v3d_sgbm* h, int enable)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    if (enable && h->prof_ev.empty()) {
+        V3D_HIP_CHECK(hipSetDevice(h->device));
+        h->prof_ev.resize((size_t)V3D_PROF_MAX_CALLS * (V3D_NSTAGE + 1));
+        for (auto& e : h->prof_ev) V3D_HIP_CHECK(hipEventCreate(&e));
+    }
+    h->prof_on = enable != 0;
+    h->prof_calls = 0;
+    return V3D_OK;
+}
+extern "C" int v3d_sgbm_profile_stage_count(void) { return V3D_NSTAGE; }
+extern "C" const char* v3d_sgbm_profile_stage_name(int i) { return (i >= 0 && i < V3D_NSTAGE) ? g_stage_names[i] : ""; }
+// total_ms[i] = summed duration of stage i over the recorded calls; returns the number of calls (or < 0)
+extern "C" int v3d_sgbm_profile_read(v3d_sgbm* h, double* total_ms, int n)
+{
+    if (!h || !total_ms || n < V3D_NSTAGE) { v3d_set_error("bad argument"); return V3D_ERR_ARG; }
+    for (int i = 0; i < V3D_NSTAGE; i++) total_ms[i] = 0.0;
+    for (int c = 0; c < h->prof_calls; c++)
+        for (int i = 0; i < V3D_NSTAGE; i++) {
+            float ms = 0.f;
+            const hipEvent_t a = h->prof_ev[(size_t)c * (V3D_NSTAGE + 1) + i], b = h->prof_ev[(size_t)c * (V3D_NSTAGE + 1) + i + 1];
+            V3D_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+            total_ms[i] += ms;
+        }
+    return h->prof_calls;
 }
 
 extern "C" int v3d_sgbm_compute(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int W, int H, int pitch, int16_t* out, void* stream)
@@ -681,13 +804,5 @@ extern "C" int v3d_median3x3_i16(const int16_t* src, int W, int H, int16_t* dst,
 extern "C" int v3d_filter_speckles(int16_t* img, int W, int H, int newVal, int maxSize, int maxDiff, int32_t* ws, void* stream)
 {
     if (!img || !ws || W < 1 || H < 1) { v3d_set_error("bad argument"); return V3D_ERR_ARG; }
-    hipStream_t st = (hipStream_t)stream;
-    const int px = W * H;
-    int* lab = ws; int* size = ws + px;
-    hipLaunchKernelGGL(k_ccl_init, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, img, px, newVal, lab, size);
-    hipLaunchKernelGGL(k_ccl_merge, dim3(v3d_cdiv(W, 256), H, 1), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
-    hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, px, maxSize, lab, size);
-    hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, 1), dim3(256), 0, st, img, px, newVal, maxSize, lab, size);
-    V3D_LAUNCH_CHECK();
-    return V3D_OK;
+    return launch_speckles(img, W, H, 1, newVal, maxSize, maxDiff, ws, (hipStream_t)stream);
 }

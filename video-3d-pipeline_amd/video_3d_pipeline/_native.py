@@ -21,6 +21,7 @@ EXPORTS = (
     "v3d_median3x3_i16", "v3d_filter_speckles", "v3d_sbs_to_gray", "v3d_split_sbs", "v3d_disp_to_depth",
     "v3d_depth_to_u16", "v3d_guided_upscale_ws_bytes", "v3d_guided_upscale", "v3d_bgr_to_gray",
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
+    "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
 )
 
 
@@ -59,6 +60,10 @@ def lib():
         L.v3d_sgbm_workspace_bytes.argtypes = [vp]
         L.v3d_sgbm_workspace_bytes.restype = sz
         L.v3d_sgbm_compute.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
+        L.v3d_sgbm_profile.argtypes = [vp, ci]
+        L.v3d_sgbm_profile_stage_name.argtypes = [ci]
+        L.v3d_sgbm_profile_stage_name.restype = C.c_char_p
+        L.v3d_sgbm_profile_read.argtypes = [vp, C.POINTER(C.c_double), ci]
         L.v3d_sgbm_compute_batch.argtypes = [vp, vp, vp, ci, ci, ci, ci, sz, vp, vp]
         L.v3d_sgbm_debug_cost_volume.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
         L.v3d_sgbm_debug_raw.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
@@ -151,6 +156,19 @@ class StereoSGBM:
                    "v3d_sgbm_compute_batch")
         return out if batched else o3[0]
 
+    def profile(self, enable=True):
+        """per-stage HIP-event timing on the current stream: enable, run compute(), synchronize, read_profile()"""
+        _check(lib().v3d_sgbm_profile(self._h, int(bool(enable))), "v3d_sgbm_profile")
+
+    def read_profile(self):
+        """-> (calls, {stage: total_ms}) ; the stream must be synchronised first"""
+        n = lib().v3d_sgbm_profile_stage_count()
+        buf = (C.c_double * n)()
+        calls = lib().v3d_sgbm_profile_read(self._h, buf, n)
+        if calls < 0:
+            _check(calls, "v3d_sgbm_profile_read")
+        return calls, {lib().v3d_sgbm_profile_stage_name(i).decode(): buf[i] for i in range(n)}
+
     def debug_cost_volume(self, left, right):
         H, W = left.shape
         out = torch.empty((H, W - 64, 64), dtype=torch.int16, device=left.device)
@@ -179,7 +197,7 @@ def median3x3(img):
 def filter_speckles(img, new_val=-16, max_size=100, max_diff=512):
     H, W = img.shape
     out = img.clone()
-    ws = torch.empty(2 * H * W, dtype=torch.int32, device=img.device)
+    ws = torch.empty(3 * H * W, dtype=torch.int32, device=img.device)
     _check(lib().v3d_filter_speckles(_dev(out, torch.int16, "img"), W, H, new_val, max_size, max_diff,
                                      _dev(ws, torch.int32, "ws"), _stream()), "v3d_filter_speckles")
     return out
