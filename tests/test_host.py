@@ -1,0 +1,232 @@
+"""Host logic of the drop-in surface (depth.py / upscale.py mirror) on CPU.  The HIP backend needs a GPU,
+so these tests inject a stand-in backend built on the oracle: they exercise the plumbing (cache naming,
+streaming, batching, PNG formats, CLI, error behaviour), not the kernels."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+class OracleStereoBackend:
+    """test-only stand-in for HipStereoBackend"""
+
+    def split_sbs(self, f, unsqueeze):
+        return O.split_sbs(f, unsqueeze)
+
+    def pairs_to_disparity(self, pairs):
+        return [O.disp_to_depth(O.sgbm_compute(O.bgr_to_gray(l), O.bgr_to_gray(r))) for l, r in pairs]
+
+    def sbs_to_disparity(self, frames, unsqueeze):
+        out = []
+        for f in frames:
+            l, r = O.sbs_to_gray(f, unsqueeze)
+            out.append(O.disp_to_depth(O.sgbm_compute(l, r)))
+        return np.stack(out)
+
+    def normalise_u16(self, depth):
+        return O.depth_to_u16(np.asarray(depth, np.float32))
+
+
+class _FakeTensor:
+    def __init__(self, a):
+        self.a = a
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self.a
+
+
+class OracleUpscaleBackend:
+    device = "cpu"
+
+    class torch:                                   # the tiny subset upscale.py touches
+        @staticmethod
+        def is_tensor(x):
+            return False
+
+    def to_luma(self, frame):
+        return _FakeTensor(frame if frame.ndim == 2 else O.bgr_to_gray(frame))
+
+    def upscale(self, depth_lo, guide, r, eps):
+        if isinstance(guide, _FakeTensor):
+            guide = guide.a
+        elif hasattr(guide, "numpy"):              # a CPU torch tensor handed back by the guide exchange
+            guide = guide.numpy()
+        g = guide if guide.ndim == 2 else O.bgr_to_gray(guide)
+        return _FakeTensor(O.guided_upscale(np.asarray(depth_lo, np.float32), g, r, eps).astype(np.float32))
+
+    def upscale_u16(self, depth_lo, guide, r, eps):
+        return np.clip(np.rint(self.upscale(depth_lo, guide, r, eps).a), 0, 65535).astype(np.uint16)
+
+    def flat_guide(self, h, w):
+        return np.full((h, w), 128, np.uint8)
+
+
+@pytest.fixture()
+def clip(tmp_path):
+    from video_3d_pipeline import synthetic as syn
+    frames = np.stack([syn.sbs_frame(192, 48, i) for i in range(5)])
+    p = tmp_path / "clip.npy"
+    np.save(p, frames)
+    return str(p), frames
+
+
+def test_both_class_names_are_exported():
+    import video_3d_pipeline as v
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor, IGEVStereoDepthExtractor
+    assert IGEVStereoDepthExtractor is HybridStereoDepthExtractor          # run_pipeline.py:12 / reference __init__.py:6
+    assert v.SimpleDepthUpscaler and v.VideoAligner and v.get_video_info
+
+
+def test_no_gpu_fails_loudly(tmp_path):
+    import torch
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="CUDA not available but requested"):        # depth.py:43-44
+        HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"))
+    with pytest.raises(RuntimeError):
+        HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), device="cpu")
+
+
+def test_cache_path_format_is_byte_identical(tmp_path):
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "c"), backend=OracleStereoBackend())
+    p = ex.get_cache_path("movie.mp4", 3, 17)
+    key = "movie.mp4_3_17_Intel/dpt-large_True"                                        # depth.py:119
+    assert p == tmp_path / "c" / f"depth_{hashlib.md5(key.encode()).hexdigest()[:16]}"
+    assert p.is_dir() and not ex.is_cached(p, 2)
+    for i in range(2):
+        (p / f"depth_{i:06d}.png").write_bytes(b"x")
+    assert ex.is_cached(p, 2) and not ex.is_cached(p, 3)
+
+
+def test_split_and_batch_numpy_surface(tmp_path, clip):
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    _, frames = clip
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), stereo_only=True,
+                                    backend=OracleStereoBackend())
+    left, right = ex.split_sbs_frame(frames[0], unsqueeze=True)
+    assert left.shape == frames[0].shape and right.shape == frames[0].shape
+    l2, r2 = ex.split_sbs_frame(frames[0], unsqueeze=False)
+    assert l2.shape == (48, 96, 3)
+    with pytest.raises(ValueError, match="SBS frame width must be even"):               # depth.py:254-255
+        ex.split_sbs_frame(np.zeros((4, 7, 3), np.uint8))
+    out = ex.process_frame_batch([(left, right)])
+    assert len(out) == 1 and out[0].dtype == np.float32 and out[0].shape == (48, 192) and out[0].min() >= 0
+    assert (out[0][:, :64] == 0).all()
+    pp = ex.preprocess_frame_pair(left, right)
+    assert np.array_equal(pp["stereo_pair"]["left"], left[..., ::-1])                   # BGR -> RGB
+    assert ex.process_frame_batch([]) == []
+
+
+def test_neural_guidance_falls_back_to_stereo_only(tmp_path, capsys):
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), backend=OracleStereoBackend())
+    assert not ex.stereo_only
+    ex.load_model()
+    assert ex.stereo_only and ex.model_loaded                                           # depth.py:107-114
+    assert "falling back to stereo-only" in capsys.readouterr().out
+
+
+def test_process_video_sbs_writes_normalised_png16(tmp_path, clip):
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.utils import read_png16
+    path, frames = clip
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), batch_size=2,
+                                    stereo_only=True, backend=OracleStereoBackend())
+    out = ex.process_video_sbs(path, start_frame=1, max_frames=3)
+    files = sorted(os.listdir(out))
+    assert files == [f"depth_{i:06d}.png" for i in range(3)]
+    l, r = O.sbs_to_gray(frames[1], True)
+    depth = O.disp_to_depth(O.sgbm_compute(l, r))
+    want = ((depth - depth.min()) / (depth.max() - depth.min()) * 65535).astype(np.uint16)   # depth.py:401
+    got = read_png16(out / "depth_000000.png")
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+    # cached: a second call must not recompute
+    ex.backend = None
+    assert ex.process_video_sbs(path, start_frame=1, max_frames=3) == out
+    with pytest.raises(ValueError, match="Could not read video info"):                   # depth.py:420
+        ex.process_video_sbs(str(tmp_path / "missing.mp4"))
+
+
+def test_depth_cli_exit_codes(tmp_path, capsys):
+    import torch
+    from video_3d_pipeline import depth
+    rc = depth.main([str(tmp_path / "nope.mp4"), "--work-dir", str(tmp_path / "w"), "--stereo-only"])
+    assert rc == 1 and "Error:" in capsys.readouterr().out                                # depth.py:534-536
+    if not torch.cuda.is_available():
+        rc = depth.main([str(tmp_path / "nope.mp4"), "--work-dir", str(tmp_path / "w"), "--device", "cpu"])
+        assert rc == 1
+    with pytest.raises(SystemExit):
+        depth.main(["--definitely-not-a-flag"])
+
+
+def test_video_info_and_frame_sources(tmp_path, clip):
+    from video_3d_pipeline.utils import get_video_info, iter_frames, write_png16, read_png16, create_work_directory
+    path, frames = clip
+    info = get_video_info(path)
+    assert info["width"] == 192 and info["height"] == 48 and info["frames"] == 5 and info["fps"] > 0
+    assert get_video_info(str(tmp_path / "none.mp4")) is None                             # utils.py:36-38
+    got = list(iter_frames(path, 2, 2))
+    assert len(got) == 2 and np.array_equal(got[0], frames[2])
+    d = create_work_directory(str(tmp_path / "frames"))
+    from PIL import Image
+    for i in range(3):
+        Image.fromarray(frames[i][..., ::-1]).save(d / f"frame_{i:06d}.png")
+    (d / "info.json").write_text(json.dumps({"fps": 24.0}))
+    info = get_video_info(str(d))
+    assert info["frames"] == 3 and info["fps"] == 24.0 and info["width"] == 192
+    assert np.array_equal(next(iter_frames(str(d), 1, 1)), frames[1])
+    a = (np.arange(12, dtype=np.uint16) * 5000).reshape(3, 4)
+    write_png16(tmp_path / "x.png", a)
+    assert np.array_equal(read_png16(tmp_path / "x.png"), a)
+
+
+def test_upscaler_flow_with_manifest(tmp_path):
+    from video_3d_pipeline.upscale import SimpleDepthUpscaler
+    from video_3d_pipeline.utils import write_png16, read_png16
+    from video_3d_pipeline import synthetic as syn
+    ddir = tmp_path / "depth_abc"
+    ddir.mkdir()
+    rng = np.random.default_rng(0)
+    lows = [(rng.uniform(0, 65535, (20, 32))).astype(np.uint16) for _ in range(2)]
+    for i, a in enumerate(lows):
+        write_png16(ddir / f"depth_{i:06d}.png", a)
+    guides = np.stack([np.repeat(syn.guide_frame(32, 20, i)[..., None], 3, axis=2) for i in range(2)])
+    v4k = tmp_path / "v4k.npy"
+    np.save(v4k, guides)
+    up = SimpleDepthUpscaler(use_nvenc=True, backend=OracleUpscaleBackend())
+    out = up.process_depth_upscaling(str(ddir), str(v4k), output_path=str(tmp_path / "final.mp4"))
+    assert os.path.exists(out)
+    man = json.loads(open(out).read())
+    assert man["count"] == 2 and man["width"] == 64 and man["height"] == 40
+    q = read_png16(os.path.join(man["frames_dir"], "depth4k_000001.png"))
+    want = O.guided_upscale(lows[1].astype(np.float32), O.bgr_to_gray(guides[1]), 8, 1e-3)
+    assert q.shape == (40, 64) and np.abs(q.astype(np.float64) - np.clip(np.rint(want), 0, 65535)).max() <= 1
+    # skip-if-exists (upscale.py:105-107) and the error paths
+    assert up.process_depth_upscaling(str(ddir), str(v4k), output_path=out) == out
+    with pytest.raises(ValueError, match="No depth maps found"):                          # upscale.py:38
+        up.upscale_depth_maps_ffmpeg(str(tmp_path), 64, 40, str(tmp_path / "o.mp4"))
+    with pytest.raises(ValueError, match="Could not read video info"):
+        up.process_depth_upscaling(str(ddir), str(tmp_path / "missing.mp4"))
+    q1 = up.upscale_frame(lows[0].astype(np.float32), guides[0])
+    assert q1.shape == (40, 64) and q1.dtype == np.float32
+
+
+def test_upscale_cli_error_exit(tmp_path, capsys):
+    from video_3d_pipeline import upscale
+    rc = upscale.main([str(tmp_path), str(tmp_path / "none.mp4")])
+    assert rc == 1 and "Error:" in capsys.readouterr().out
+
+
+def test_aligner_stub_is_explicit():
+    from video_3d_pipeline.align import VideoAligner
+    with pytest.raises(RuntimeError, match="skip-alignment"):
+        VideoAligner("a", "b").find_alignment(300)

@@ -43,6 +43,15 @@ class HipUpscaleBackend:
         g = self.to_luma(guide)
         return nat.guided_upscale(d.contiguous(), g.contiguous(), r, eps)
 
+    def upscale_u16(self, depth_lo, guide, r, eps) -> np.ndarray:
+        """guided upscale, rounded and clamped to the 16-bit range of the PNG sink"""
+        torch = self.torch
+        q = self.upscale(depth_lo, guide, r, eps)
+        return torch.clamp(torch.round(q), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
+
+    def flat_guide(self, h, w):
+        return self.torch.full((h, w), 128, dtype=self.torch.uint8, device=self.device)
+
 
 class SimpleDepthUpscaler:
     """ Depth upscaling to the 4K frame (guided filter on the GPU) """
@@ -77,7 +86,6 @@ class SimpleDepthUpscaler:
         rank, world = sharding.rank_world()
         frames_dir = Path(str(Path(output_path).with_suffix("")) + "_frames")
         frames_dir.mkdir(parents=True, exist_ok=True)
-        torch = self.backend.torch
         guides = iter_frames(video_4k_path, 0, len(depth_files)) if (video_4k_path and rank == 0) else None
         n = len(depth_files)
         for base in range(0, n, world):
@@ -95,10 +103,8 @@ class SimpleDepthUpscaler:
                 continue
             d16 = read_png16(depth_files[i]).astype(np.float32)
             if guide is None:     # no 4K frame for this index: guide with a flat image == plain smoothing upsample
-                guide = torch.full((target_height, target_width), 128, dtype=torch.uint8, device=self.backend.device)
-            q = self.backend.upscale(d16, guide, self.radius, self.eps)
-            q16 = torch.clamp(torch.round(q), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
-            write_png16(frames_dir / f"depth4k_{i:06d}.png", q16)
+                guide = self.backend.flat_guide(target_height, target_width)
+            write_png16(frames_dir / f"depth4k_{i:06d}.png", self.backend.upscale_u16(d16, guide, self.radius, self.eps))
         sharding.barrier()
 
         if rank == 0:
