@@ -102,6 +102,9 @@ int v3d_filter_speckles(int16_t* img, int W, int H, int newVal, int maxSpeckleSi
    unsqueeze != 0: outputs are W x H (Lanczos4 x2 horizontal); else (W/2) x H. W must be even. */
 int v3d_sbs_to_gray(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze,
                     uint8_t* left_gray, uint8_t* right_gray, void* stream);
+/* n frames in one launch: frame f at sbs_bgr + f*frame_stride bytes; outputs packed [n][H][outW] */
+int v3d_sbs_to_gray_batch(const uint8_t* sbs_bgr, int n, int W, int H, int pitch, size_t frame_stride,
+                          int unsqueeze, uint8_t* left_gray, uint8_t* right_gray, void* stream);
 /* the BGR halves themselves (split_sbs_frame's return value), [H][outW][3] */
 int v3d_split_sbs(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze,
                   uint8_t* left_bgr, uint8_t* right_bgr, void* stream);
@@ -115,6 +118,11 @@ int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, float* minmax_
 size_t v3d_guided_upscale_ws_bytes(int Whi, int Hhi);
 int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int Whi, int Hhi,
                        int r, float eps, float* out, void* ws, void* stream);
+/* n frames in one launch: frame f at depth_lo + f*depth_stride (floats), guide + f*guide_stride (bytes),
+   out + f*Whi*Hhi; ws must hold n * v3d_guided_upscale_ws_bytes(Whi, Hhi) bytes */
+int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
+                             int Whi, int Hhi, size_t guide_stride, int n, int r, float eps, float* out,
+                             void* ws, void* stream);
 /* BGR [H][W][3] u8 -> luma u8 with the same weights as cvtColor */
 int v3d_bgr_to_gray(const uint8_t* bgr, size_t n_pixels, uint8_t* gray, void* stream);
 

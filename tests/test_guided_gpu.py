@@ -82,3 +82,16 @@ def test_rejects_bad_radius(native):
     g = native.to_device(np.zeros((20, 20), np.uint8))
     with pytest.raises(native.NativeError):
         native.guided_upscale(d, g, 40, 1e-3)
+
+
+def test_batch_with_strided_guides(native, oracle):
+    """the multi-GPU guide round buffer is [B, world, H, W]: frames of one rank are strided views"""
+    import torch
+    depths, guides = zip(*[_case(40 + i, 64, 40) for i in range(3)])
+    d = native.to_device(np.stack(depths))
+    buf = torch.zeros((3, 2, 80, 128), dtype=torch.uint8, device="cuda")
+    buf[:, 1] = native.to_device(np.stack(guides))
+    got = native.guided_upscale_batch(d, buf[:, 1], 8, 1e-3).cpu().numpy().astype(np.float64)
+    for i in range(3):
+        want = oracle.guided_upscale(depths[i], guides[i], 8, 1e-3)
+        assert _rel_err(got[i], want).max() <= RTOL

@@ -56,3 +56,12 @@ def test_disp_to_depth_and_u16(native, oracle):
     assert not mismatch_report(u, oracle.depth_to_u16(want), "u16")
     flat = native.to_device(np.full((5, 9), 3.25, np.float32))
     assert (native.depth_to_u16(flat).cpu().numpy() == 0).all()
+
+
+def test_sbs_to_gray_batch_equals_single(native, oracle):
+    rng = np.random.default_rng(8)
+    sbs = rng.integers(0, 256, (3, 21, 66, 3), dtype=np.uint8)
+    L, R = native.sbs_to_gray_batch(native.to_device(sbs), True)
+    for i in range(3):
+        wl, wr = oracle.sbs_to_gray(sbs[i], True)
+        assert not mismatch_report(L[i].cpu().numpy(), wl, f"left[{i}]") and not mismatch_report(R[i].cpu().numpy(), wr, f"right[{i}]")

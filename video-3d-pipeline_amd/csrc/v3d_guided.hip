@@ -137,6 +137,105 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path for r in {4, 8}: column-marching sweeps.  A workgroup owns a strip of 256 - 2r output
+// columns (+ r halo each side, one thread per column) and marches down a band of rows.  The vertical box
+// sums slide in REGISTERS (a compile-time ring of the last 2r+1 rows' values per column: add the entering
+// row, subtract the leaving one); only the per-row vertical sums cross lanes, through a 2 x NS x 256 f64
+// LDS row buffer, for the 2r+1-tap horizontal sum.  16 KB of LDS per workgroup -> full occupancy, one
+// barrier per row, every input element is read once per band (+ 2r warm-up rows).
+// ------------------------------------------------------------------------------------------------
+template <int SWEEP, int RR>
+__global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+                                             const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
+                                             double* __restrict__ A, double* __restrict__ B, float* __restrict__ out,
+                                             size_t depth_stride, size_t guide_stride)
+{
+    constexpr int R = 2 * RR + 1, NS = SWEEP == 1 ? 4 : 2;
+    {   // frame of the batch
+        const size_t f = blockIdx.z, n4 = (size_t)W * H;
+        depth_lo += f * depth_stride; guide += f * guide_stride; A += f * 2 * n4; B += f * 2 * n4; out += f * n4;
+    }
+    __shared__ double sV[2][NS][256];
+    const int tid = threadIdx.x;
+    const int gx = blockIdx.x * (256 - 2 * RR) - RR + tid;          // this thread's image column
+    const int ya = blockIdx.y * band_h, yb = min(ya + band_h, H);
+    const bool col_ok = gx >= 0 && gx < W;
+    const bool out_col = tid >= RR && tid < 256 - RR && gx < W;
+    const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
+    const int cx = min(gx + RR, W - 1) - max(gx - RR, 0) + 1;
+    const int nsteps = (yb - ya) + 2 * RR;
+
+    double r0[R], r1[R], v[NS];
+#pragma unroll
+    for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < NS; q++) v[q] = 0.0;
+
+    for (int t0 = 0; t0 < nsteps; t0 += R) {
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int t = t0 + j;
+            if (t < nsteps) {                                        // uniform
+                const int e = ya - RR + t;                           // row entering the window
+                double n0 = 0.0, n1 = 0.0;
+                if (col_ok && e >= 0 && e < H) {
+                    if (SWEEP == 1) {
+                        n0 = (double)guide[(size_t)e * W + gx] / 255.0;
+                        n1 = gf_bilinear(depth_lo, Wlo, Hlo, sx, sy, gx, e);
+                    } else {
+                        n0 = A[(size_t)e * W + gx];
+                        n1 = B[(size_t)e * W + gx];
+                    }
+                }
+                const double o0 = r0[j], o1 = r1[j];                 // row e - R leaves (zeros during warm-up)
+                r0[j] = n0; r1[j] = n1;
+                v[0] += n0 - o0; v[1] += n1 - o1;
+                if (SWEEP == 1) { v[2] += n0 * n0 - o0 * o0; v[3] += n0 * n1 - o0 * o1; }
+                const int y = e - RR;                                // output row whose window is now complete
+                if (y >= ya) {                                       // uniform
+                    const int buf = t & 1;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) sV[buf][q][tid] = v[q];
+                    __syncthreads();
+                    if (out_col) {
+                        double s[NS];
+#pragma unroll
+                        for (int q = 0; q < NS; q++) s[q] = 0.0;
+#pragma unroll
+                        for (int k = -RR; k <= RR; k++)
+#pragma unroll
+                            for (int q = 0; q < NS; q++) s[q] += sV[buf][q][tid + k];
+                        const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                        const double cnt = (double)(cx * cy);
+                        if (SWEEP == 1) {
+                            const double mI = s[0] / cnt, mp = s[1] / cnt, mII = s[2] / cnt, mIp = s[3] / cnt;
+                            const double var = mII - mI * mI, cov = mIp - mI * mp;
+                            const double a = cov / (var + eps);
+                            A[(size_t)y * W + gx] = a;
+                            B[(size_t)y * W + gx] = mp - a * mI;
+                        } else {
+                            const double I = (double)guide[(size_t)y * W + gx] / 255.0;
+                            out[(size_t)y * W + gx] = (float)((s[0] / cnt) * I + (s[1] / cnt));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int RR>
+static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
+                       double* A, double* B, float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
+{
+    const char* e = getenv("V3D_GF_BAND");
+    const int band_h = e ? atoi(e) : 48;
+    const dim3 grid(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band_h), n);
+    hipLaunchKernelGGL((k_gfm<1, RR>), grid, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band_h, A, B, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gfm<2, RR>), grid, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band_h, A, B, out, depth_stride, guide_stride);
+}
+
 extern "C" size_t v3d_guided_upscale_ws_bytes(int W, int H)
 {
     if (W < 1 || H < 1) return 0;
@@ -150,9 +249,12 @@ static size_t gf_smem(int r, int ns, int ty)
     return sizeof(double) * ((size_t)2 * rows * pitch + (size_t)ns * rows * (GF_TX + 1));
 }
 
-extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H,
-                                  int r, float eps, float* out, void* ws, void* stream)
+// n frames: frame f at depth_lo + f*depth_stride (floats), guide + f*guide_stride (bytes), out + f*W*H;
+// ws must hold n * v3d_guided_upscale_ws_bytes(W, H)
+extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
+                                        int W, int H, size_t guide_stride, int n, int r, float eps, float* out, void* ws, void* stream)
 {
+    if (n < 1) { v3d_set_error("bad batch"); return V3D_ERR_ARG; }
     if (!depth_lo || !guide || !out || !ws) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
     if (Wlo < 1 || Hlo < 1 || W < 1 || H < 1) { v3d_set_error("bad geometry"); return V3D_ERR_ARG; }
     if (r < 1 || r > GF_RMAX) { v3d_set_error("radius %d outside [1, %d]", r, GF_RMAX); return V3D_ERR_UNSUPPORTED; }
@@ -160,6 +262,15 @@ extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const
     hipStream_t st = (hipStream_t)stream;
     double* A = reinterpret_cast<double*>(ws);
     double* B = A + (size_t)W * H;
+    if (!getenv("V3D_GF_TILED") && (r == 4 || r == 8)) {     // larger rings spill: r = 16 takes the tiled kernel
+        if (r == 4) launch_gfm<4>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
+        else launch_gfm<8>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
+        V3D_LAUNCH_CHECK();
+        return V3D_OK;
+    }
+    for (int f = 0; f < n; f++) {
+    const float* depth_lo_f = depth_lo + (size_t)f * depth_stride; const uint8_t* guide_f = guide + (size_t)f * guide_stride;
+    double* A = reinterpret_cast<double*>(ws) + (size_t)f * 2 * W * H; double* B = A + (size_t)W * H; float* out_f = out + (size_t)f * W * H;
     const int ty = r <= 8 ? 16 : 8;
     const dim3 grid(v3d_cdiv(W, GF_TX), v3d_cdiv(H, ty));
     const size_t sm1 = gf_smem(r, 4, ty), sm2 = gf_smem(r, 2, ty);
@@ -167,14 +278,21 @@ extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const
         // above the default dynamic-LDS limit: opt in (160 KiB per CU on gfx950)
         V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
         V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
-        hipLaunchKernelGGL((k_gf<1, 4>), grid, dim3(256), sm1, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
-        hipLaunchKernelGGL((k_gf<2, 4>), grid, dim3(256), sm2, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
+        hipLaunchKernelGGL((k_gf<1, 4>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        hipLaunchKernelGGL((k_gf<2, 4>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
     } else {
         V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
         V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
-        hipLaunchKernelGGL((k_gf<1, 2>), grid, dim3(256), sm1, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
-        hipLaunchKernelGGL((k_gf<2, 2>), grid, dim3(256), sm2, st, depth_lo, Wlo, Hlo, guide, W, H, r, (double)eps, A, B, out);
+        hipLaunchKernelGGL((k_gf<1, 2>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        hipLaunchKernelGGL((k_gf<2, 2>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+    }
     }
     V3D_LAUNCH_CHECK();
     return V3D_OK;
+}
+
+extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H,
+                                  int r, float eps, float* out, void* ws, void* stream)
+{
+    return v3d_guided_upscale_batch(depth_lo, Wlo, Hlo, 0, guide, W, H, 0, 1, r, eps, out, ws, stream);
 }

@@ -35,11 +35,15 @@ __device__ __forceinline__ int gray_of(int b, int g, int r) { return (r * 9798 +
 // one thread = one output pixel of one eye.  GRAY: write luma only; else write the BGR triple.
 template <bool GRAY>
 __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ sbs, int W, int H, int pitch, int unsqueeze,
-                                                   LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR)
+                                                   LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR,
+                                                   size_t in_stride)
 {
     const int hw = W >> 1, ow = unsqueeze ? W : hw;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, eye = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, eye = blockIdx.z & 1, f = blockIdx.z >> 1;
     if (x >= ow) return;
+    sbs += (size_t)f * in_stride;
+    const size_t ostride = (size_t)ow * H * (GRAY ? 1 : 3);
+    outL += f * ostride; outR += f * ostride;
     const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;
     int b, g, r;
     if (unsqueeze) {
@@ -64,8 +68,9 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
     else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
 }
 
-static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, bool gray, hipStream_t st)
+static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, bool gray, int n, size_t in_stride, hipStream_t st)
 {
+    if (n < 1) { v3d_set_error("bad batch"); return V3D_ERR_ARG; }
     if (!sbs || !L || !R) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
     if (W % 2 != 0) { v3d_set_error("SBS frame width must be even"); return V3D_ERR_ARG; }
     if (W < 2 || H < 1 || pitch < W * 3) { v3d_set_error("bad SBS geometry %dx%d pitch %d", W, H, pitch); return V3D_ERR_ARG; }
@@ -73,19 +78,24 @@ static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsquee
     lanczos4_taps_host(0.75f, taps.t[0]);
     lanczos4_taps_host(0.25f, taps.t[1]);
     const int ow = unsqueeze ? W : W / 2;
-    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), H, 2), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R);
-    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), H, 2), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R);
+    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), H, 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
+    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), H, 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
 
 extern "C" int v3d_sbs_to_gray(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, void* stream)
 {
-    return split_common(sbs, W, H, pitch, unsqueeze, L, R, true, (hipStream_t)stream);
+    return split_common(sbs, W, H, pitch, unsqueeze, L, R, true, 1, 0, (hipStream_t)stream);
 }
 extern "C" int v3d_split_sbs(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, void* stream)
 {
-    return split_common(sbs, W, H, pitch, unsqueeze, L, R, false, (hipStream_t)stream);
+    return split_common(sbs, W, H, pitch, unsqueeze, L, R, false, 1, 0, (hipStream_t)stream);
+}
+// n frames: frame f at sbs + f*frame_stride (bytes); outputs packed [n][H][outW]
+extern "C" int v3d_sbs_to_gray_batch(const uint8_t* sbs, int n, int W, int H, int pitch, size_t frame_stride, int unsqueeze, uint8_t* L, uint8_t* R, void* stream)
+{
+    return split_common(sbs, W, H, pitch, unsqueeze, L, R, true, n, frame_stride, (hipStream_t)stream);
 }
 
 __global__ __launch_bounds__(256) void k_bgr_to_gray(const uint8_t* __restrict__ bgr, size_t n, uint8_t* __restrict__ gray)

@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ i
 // (+2 halo each side) marching down a band of rows; lane = (column, 4 disparities).
 // Per row: BT cost bytes -> LDS row, 5-tap horizontal sum from LDS, 5-row vertical sum in registers.
 // ------------------------------------------------------------------------------------------------
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t delta, const uint32_t (&c)[NP],
+                                               uint32_t (&L)[NP], uint32_t P1pk, uint32_t P2pk, bool first_lane, bool last_lane);
+
 #define COST_COLS 32
 #define COST_OUT 28
 #define COST_NREC 96
@@ -71,11 +75,20 @@ __device__ __forceinline__ uint32_t byte2(uint32_t a, int sa, uint32_t b, int sb
     return ((a >> sa) & 0xFFu) | (((b >> sb) & 0xFFu) << 16);
 }
 
+// FUSE_V: the band is the whole image and the vertical SGM path r2 = (x, y-1) rides along: the lane
+// layout (16 lanes x 4 disparities per pixel = one DPP row) is exactly k_chain's DPL = 4 mapping, so
+// C goes from registers straight into chain_step and S = L_r2 is written next to C (saves one full
+// read of C and a launch).
+template <bool FUSE_V>
 __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, const uint2* __restrict__ rec2,
-                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C)
+                                              int W, int H, int W1, int band_h, int P1, int P2, int16_t* __restrict__ C,
+                                              int16_t* __restrict__ S)
 {
-    __shared__ uint2 sR[2][COST_NREC];
-    __shared__ uint2 sL[2][COST_COLS];
+    // right-image planes of one row, per quantity, as REVERSED u16 arrays (index grows with d) in two
+    // alignments (copy 1 is copy 0 shifted by one element) so that the packed pair (d, d+1) is always an
+    // aligned dword: no byte extraction in the hot loop.  Left-image values are stored pre-broadcast.
+    __shared__ __attribute__((aligned(8))) unsigned short sRV[2][2][6][COST_NREC + 4];
+    __shared__ __attribute__((aligned(8))) uint32_t sUL[2][COST_COLS][6];
     __shared__ uint32_t sPix[2][COST_COLS][16];
 
     const int tid = threadIdx.x, col = tid >> 4, dq = tid & 15;
@@ -87,44 +100,65 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
     int16_t* Cf = C + (size_t)f * H * W1 * V3D_D;
 
     const int xrc = min(max(xr0 - 2 + col, 0), W1 - 1);        // clamped cost-region column of this lane
-    const int i0 = xrc - xr0 + 65 - 4 * dq;                    // staged index of the right record for d = 4*dq
+    // staged record i <-> image column xr0 - 1 + i; reversed element k = 95 - i.  d = 4dq + j reads record
+    // i0 - j with i0 = xrc - xr0 + 65 - 4dq, i.e. reversed elements k0 + j, k0 = 30 - (xrc - xr0) + 4dq.
+    const int k0 = 30 - (xrc - xr0) + 4 * dq;
+    const int rcopy = k0 & 1, rk = k0 - rcopy;                  // even element offset inside copy `rcopy`
     const bool out_col = (col >= 2) && (col < 2 + COST_OUT) && (xr0 - 2 + col < W1);
     const int nrows = (ye - ys) + 4;
 
-    // which record this thread stages per row (threads 0..95: right image, 96..127: left image)
-    int ld_x = 0; const uint2* ld_src = nullptr; uint2* ld_dst0 = nullptr; uint2* ld_dst1 = nullptr;
-    if (tid < COST_NREC) {
-        ld_x = min(max(xr0 - 1 + tid, 0), W - 1); ld_src = r2; ld_dst0 = &sR[0][tid]; ld_dst1 = &sR[1][tid];
-    } else if (tid < COST_NREC + COST_COLS) {
-        const int c = tid - COST_NREC;
-        ld_x = min(max(xr0 - 2 + c, 0), W1 - 1) + V3D_D; ld_src = r1; ld_dst0 = &sL[0][c]; ld_dst1 = &sL[1][c];
-    }
-    if (ld_src) *ld_dst0 = ld_src[(size_t)min(max(ys - 2, 0), H - 1) * W + ld_x];
+    // which record this thread stages per row (threads 0..95: right image, 96..127: left image).
+    // Records are fetched three rows ahead of their use so the wait for row k+1's record can leave the
+    // youngest loads and the C stores of the last rows in flight (vmcnt counts stores too on CDNA).
+    // (A dedicated 9th staging wave was tried: 576-thread blocks drop a workgroup per CU and lose.)
+    int ld_x = 0; const uint2* ld_src = nullptr;
+    const bool ld_right = tid < COST_NREC, ld_left = tid >= COST_NREC && tid < COST_NREC + COST_COLS;
+    if (ld_right) { ld_x = min(max(xr0 - 1 + tid, 0), W - 1); ld_src = r2; }
+    else if (ld_left) { ld_x = min(max(xr0 - 2 + (tid - COST_NREC), 0), W1 - 1) + V3D_D; ld_src = r1; }
+    auto stage = [&](int b, uint2 rec) {
+        const uint32_t q[6] = { rec.x & 0xFFu, (rec.x >> 8) & 0xFFu, (rec.x >> 16) & 0xFFu, rec.x >> 24, rec.y & 0xFFu, (rec.y >> 8) & 0xFFu };
+        if (ld_right) {
+            const int k = COST_NREC - 1 - tid;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { sRV[b][0][i][k] = (unsigned short)q[i]; if (k > 0) sRV[b][1][i][k - 1] = (unsigned short)q[i]; }
+        } else if (ld_left) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) sUL[b][tid - COST_NREC][i] = q[i] * 0x00010001u;
+        }
+    };
+    auto fetch = [&](int k) -> uint2 {
+        return ld_src ? ld_src[(size_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W + ld_x] : make_uint2(0, 0);
+    };
+    if (ld_src) stage(0, fetch(0));
+    uint2 n1 = fetch(1), n2 = fetch(2), n3 = fetch(3);
     __syncthreads();
 
     uint32_t hE0 = 0, hE1 = 0, hE2 = 0, hE3 = 0, hO0 = 0, hO1 = 0, hO2 = 0, hO3 = 0;
-    const uint32_t P2pk = pk_bcast(P2);
+    const uint32_t P2pk = pk_bcast(P2), P1pk = pk_bcast(P1);
+    uint32_t vp[2] = { 0u, 0u }, vdelta = P2pk;                 // vertical path state (FUSE_V)
+    int16_t* Sf = FUSE_V ? S + (size_t)f * H * W1 * V3D_D : nullptr;
 
     for (int k = 0; k < nrows; k++) {
         const int buf = k & 1;
-        uint2 nxt = make_uint2(0, 0);
-        const bool more = (k + 1 < nrows);
-        if (more && ld_src) nxt = ld_src[(size_t)min(max(ys - 2 + k + 1, 0), H - 1) * W + ld_x];
+        const uint2 n4 = fetch(k + 4);
 
-        // ---- BT cost of (xrc, d = 4dq .. 4dq+3) on row clamp(ys - 2 + k) ----
-        const uint2 L = sL[buf][col];
-        const uint2 A = sR[buf][i0], B = sR[buf][i0 - 1], Cc = sR[buf][i0 - 2], Dd = sR[buf][i0 - 3];
-        const uint32_t Ug = pk_bcast(L.x & 0xFF), Ug0 = pk_bcast((L.x >> 8) & 0xFF), Ug1 = pk_bcast((L.x >> 16) & 0xFF);
-        const uint32_t Ur = pk_bcast(L.x >> 24), Ur0 = pk_bcast(L.y & 0xFF), Ur1 = pk_bcast((L.y >> 8) & 0xFF);
-        // pair (d0, d0+1): records A, B ; pair (d0+2, d0+3): records Cc, Dd
-        uint32_t g01 = bt_pair(Ug, Ug0, Ug1, byte2(A.x, 0, B.x, 0), byte2(A.x, 8, B.x, 8), byte2(A.x, 16, B.x, 16));
-        uint32_t r01 = bt_pair(Ur, Ur0, Ur1, byte2(A.x, 24, B.x, 24), byte2(A.y, 0, B.y, 0), byte2(A.y, 8, B.y, 8));
-        uint32_t g23 = bt_pair(Ug, Ug0, Ug1, byte2(Cc.x, 0, Dd.x, 0), byte2(Cc.x, 8, Dd.x, 8), byte2(Cc.x, 16, Dd.x, 16));
-        uint32_t r23 = bt_pair(Ur, Ur0, Ur1, byte2(Cc.x, 24, Dd.x, 24), byte2(Cc.y, 0, Dd.y, 0), byte2(Cc.y, 8, Dd.y, 8));
+        // ---- BT cost of (xrc, d = 4dq .. 4dq+3) on row clamp(ys - 2 + k): quantities g, g_lo, g_hi, r, r_lo, r_hi ----
+        uint32_t U[6], V01[6], V23[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            U[i] = sUL[buf][col][i];
+            const uint32_t* pr = reinterpret_cast<const uint32_t*>(&sRV[buf][rcopy][i][rk]);
+            V01[i] = pr[0]; V23[i] = pr[1];
+        }
+        const uint32_t g01 = bt_pair(U[0], U[1], U[2], V01[0], V01[1], V01[2]);
+        const uint32_t r01 = bt_pair(U[3], U[4], U[5], V01[3], V01[4], V01[5]);
+        const uint32_t g23 = bt_pair(U[0], U[1], U[2], V23[0], V23[1], V23[2]);
+        const uint32_t r23 = bt_pair(U[3], U[4], U[5], V23[3], V23[4], V23[5]);
         const uint32_t p01 = g01 + pk_shr_u(r01, 2), p23 = g23 + pk_shr_u(r23, 2);      // each half <= 93
-        sPix[buf][col][dq] = (p01 & 0xFFu) | ((p01 >> 16) << 8) | ((p23 & 0xFFu) << 16) | ((p23 >> 16) << 24);
+        sPix[buf][col][dq] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);               // bytes d0, d1, d2, d3
 
-        if (more && ld_src) *(buf ? ld_dst0 : ld_dst1) = nxt;
+        if (k + 1 < nrows && ld_src) stage(buf ^ 1, n1);
+        n1 = n2; n2 = n3; n3 = n4;
         __syncthreads();
 
         // ---- 5-tap horizontal sum (bytes d0..d3 -> (d0,d2) / (d1,d3) u16 pairs), 5-row vertical sum ----
@@ -141,7 +175,15 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
                 o.x = (cE & 0xFFFFu) | (cO << 16);
                 o.y = (cE >> 16) | (cO & 0xFFFF0000u);
                 const int y = ys + k - 4;
-                *reinterpret_cast<uint2*>(Cf + ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq) = o;
+                const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq;
+                *reinterpret_cast<uint2*>(Cf + off) = o;
+                if (FUSE_V) {
+                    const uint32_t cv[2] = { o.x, o.y };
+                    uint32_t L[2];
+                    vdelta = chain_step<2, 16>(vp, vdelta, cv, L, P1pk, P2pk, dq == 0, dq == 15);
+                    vp[0] = L[0]; vp[1] = L[1];
+                    *reinterpret_cast<uint2*>(Sf + off) = make_uint2(L[0], L[1]);
+                }
             }
             hE3 = hE2; hE2 = hE1; hE1 = hE0; hE0 = hE;
             hO3 = hO2; hO2 = hO1; hO1 = hO0; hO0 = hO;
@@ -375,6 +417,123 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// a-5/a-6, both horizontal paths + WTA in ONE launch (saves an S write, an S read and a C read per
+// frame versus k_chain<H0, mode 1> + k_chain<H4, mode 2>).  The final S needs L_left(x) and L_right(x)
+// of the same pixel, but the two recurrences run in opposite directions and a row of L (237 KB) fits
+// nowhere on chip.  So: phase 1 sweeps left->right reading only C and drops a CHECKPOINT of the path
+// state (DPL/2 + 1 registers per lane) every K pixels into a small global buffer; phase 2 walks the
+// K-pixel blocks right->left: restore the checkpoint, recompute L_left for the block into registers,
+// run L_right backwards over it, form S + L_left + L_right on chip and do the WTA tail.
+// Cost: L_left is computed twice (+1 path of VALU), C is read twice, S once, never written.
+// ------------------------------------------------------------------------------------------------
+template <int DPL>
+__global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restrict__ ckpt)
+{
+    constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW, PF = 4;
+    typedef typename VecT<DPL>::type Vec;
+    __shared__ __attribute__((aligned(16))) unsigned char sS[4 * 64 * WTA_ROWB];
+
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int W1 = a.W1, H = a.H;
+    const int groups = (H + PPW - 1) / PPW;
+    const int gw = blockIdx.x * 4 + wib;
+    const int frame = gw / groups, grp = gw - frame * groups;
+    if (frame >= a.nframes) return;                            // wave-uniform; no block-wide barriers below
+
+    const int sub = lane / LPP, dl = lane % LPP;
+    const int c0 = grp * PPW, c1 = min(c0 + PPW, H) - 1;
+    const int cc = min(c0 + sub, c1);
+    const int16_t* Crow = a.C + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
+    const int16_t* Srow = a.S + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
+    const int nblk = (W1 + K - 1) / K;
+    uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * (NP + 1) * 64 + lane;   // [blk][reg][lane]
+
+    const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
+    const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
+
+    // ---------------- phase 1: left -> right over blocks 0 .. nblk-2, checkpoint at every block start ----------------
+    {
+        uint32_t p[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) p[i] = 0;
+        uint32_t delta = P2pk;
+        const int xend = (nblk - 1) * K;                       // the last block is recomputed in phase 2 anyway
+        Vec cq[PF];
+#pragma unroll
+        for (int j = 0; j < PF; j++) cq[j] = *reinterpret_cast<const Vec*>(Crow + (size_t)min(j, W1 - 1) * V3D_D);
+        for (int xb = 0; xb < xend; xb += K) {
+#pragma unroll
+            for (int jj = 0; jj < K; jj++) {
+                const int j = jj % PF, x = xb + jj;
+                uint32_t cv[NP], L[NP];
+                vec_unpack<NP>(cq[j], cv);
+                cq[j] = *reinterpret_cast<const Vec*>(Crow + (size_t)min(x + PF, W1 - 1) * V3D_D);
+                delta = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
+#pragma unroll
+                for (int i = 0; i < NP; i++) p[i] = L[i];
+            }
+            uint32_t* c = ck + (size_t)(xb / K + 1) * (NP + 1) * 64;
+#pragma unroll
+            for (int i = 0; i < NP; i++) c[i * 64] = p[i];
+            c[NP * 64] = delta;
+        }
+    }
+
+    // ---------------- phase 2: right -> left, block by block ----------------
+    unsigned char* myS = sS + wib * 64 * WTA_ROWB;
+    uint32_t q[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) q[i] = 0;
+    uint32_t qdelta = P2pk;
+    for (int blk = nblk - 1; blk >= 0; blk--) {
+        const int x0 = blk * K;
+        Vec cvv[K], svv[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const size_t o = (size_t)min(x0 + j, W1 - 1) * V3D_D;
+            cvv[j] = *reinterpret_cast<const Vec*>(Crow + o);
+            svv[j] = *reinterpret_cast<const Vec*>(Srow + o);
+        }
+        uint32_t p[NP], delta = P2pk;
+#pragma unroll
+        for (int i = 0; i < NP; i++) p[i] = 0;
+        if (blk > 0) {
+            const uint32_t* c = ck + (size_t)blk * (NP + 1) * 64;
+#pragma unroll
+            for (int i = 0; i < NP; i++) p[i] = c[i * 64];
+            delta = c[NP * 64];
+        }
+        uint32_t L0[K][NP];
+#pragma unroll
+        for (int j = 0; j < K; j++) {                          // forward recompute of the left path inside the block
+            uint32_t cv[NP];
+            vec_unpack<NP>(cvv[j], cv);
+            delta = chain_step<NP, LPP>(p, delta, cv, L0[j], P1pk, P2pk, first_lane, last_lane);
+#pragma unroll
+            for (int i = 0; i < NP; i++) p[i] = L0[j][i];
+        }
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {                       // right path, backwards; x >= W1 only in the last block
+            const int j = K - 1 - jj;
+            if (x0 + j < W1) {                                  // uniform
+                uint32_t cv[NP], sv[NP], L[NP];
+                vec_unpack<NP>(cvv[j], cv);
+                vec_unpack<NP>(svv[j], sv);
+                qdelta = chain_step<NP, LPP>(q, qdelta, cv, L, P1pk, P2pk, first_lane, last_lane);
+#pragma unroll
+                for (int i = 0; i < NP; i++) { q[i] = L[i]; sv[i] = pk_add_sat(pk_add_sat(sv[i], L0[j][i]), L[i]); }
+                *reinterpret_cast<Vec*>(myS + (sub * K + jj) * WTA_ROWB + dl * DPL * 2) = Packer<NP>::go(sv);
+            }
+        }
+        {
+            const int wsub = lane / K, wj = lane % K;
+            const int x = x0 + K - 1 - wj, y = c0 + wsub;
+            wta_pixel(myS + lane * WTA_ROWB, (y <= c1) && (x < W1), x, y, frame, a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a-7: L-R consistency check; also writes the always-invalid columns x < 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
@@ -562,6 +721,8 @@ struct v3d_sgbm {
     uint2 *rec1, *rec2;
     int16_t *C, *S, *dispw, *raw, *med;
     uint32_t* d2key;
+    uint32_t* ckpt;                             // k_hfused checkpoints
+    bool hfused, vfused;
     int32_t* labels;
     size_t bytes;
     // optional per-stage HIP-event timing (v3d_sgbm_profile): events live on the caller's stream
@@ -625,7 +786,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         return V3D_ERR_UNSUPPORTED;
     }
     const char* e = getenv("V3D_CHAIN_DPL");
-    h->dpl = (e && atoi(e) == 4) ? 4 : 8;
+    h->dpl = (e && atoi(e) == 8) ? 8 : 4;
     const size_t px = (size_t)maxW * maxH * maxB, vol = (size_t)(maxW - V3D_D) * maxH * V3D_D * maxB;
     h->bytes = 0;
     int rc = 0;
@@ -633,6 +794,13 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
     rc |= ws_alloc(&h->dispw, px, &h->bytes); rc |= ws_alloc(&h->raw, px, &h->bytes); rc |= ws_alloc(&h->med, px, &h->bytes);
     rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
+    {   // checkpoints: per frame, per wave (DPL rows), per K-pixel block: 64 lanes x (DPL/2 + 1) dwords
+        const int W1m = maxW - V3D_D;
+        const size_t c4 = (size_t)v3d_cdiv(maxH, 4) * v3d_cdiv(W1m, 16) * 64 * 3, c8 = (size_t)v3d_cdiv(maxH, 8) * v3d_cdiv(W1m, 8) * 64 * 5;
+        rc |= ws_alloc(&h->ckpt, (c4 > c8 ? c4 : c8) * maxB, &h->bytes);
+    }
+    { const char* e2 = getenv("V3D_HFUSED"); h->hfused = !(e2 && atoi(e2) == 0); }
+    { const char* e3 = getenv("V3D_VFUSED"); h->vfused = (e3 && atoi(e3) == 1); }   // measured: no gain at batch 8 (the unbanded kernel has too few waves); off
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
     return V3D_OK;
@@ -642,7 +810,7 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels };
+    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
@@ -687,8 +855,10 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     prof_mark(h, ST_PREFILTER, st);
     hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
     prof_mark(h, ST_COST, st);
-    const int band_h = 136;
-    hipLaunchKernelGGL(k_cost, dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, band_h), n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, band_h, h->P2, h->C);
+    const bool vf = h->vfused && last_stage != 1;
+    if (vf) hipLaunchKernelGGL(k_cost<true>, dim3(v3d_cdiv(W1, COST_OUT), 1, n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, H, h->P1, h->P2, h->C, h->S);
+    else { const int band_h = 136;
+        hipLaunchKernelGGL(k_cost<false>, dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, band_h), n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, band_h, h->P1, h->P2, h->C, h->S); }
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_V2, st);
     if (last_stage == 1) return V3D_OK;
@@ -698,13 +868,13 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     a.dispw = h->dispw; a.d2key = h->d2key;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
-    launch_chain<false, 0, false, 0>(h, a, st);         // r2: (x, y-1)
+    if (!vf) launch_chain<false, 0, false, 0>(h, a, st);    // r2: (x, y-1) (else done inside k_cost)
     prof_mark(h, ST_D1, st);
     launch_chain<false, 1, false, 1>(h, a, st);         // r1: (x-1, y-1)
     prof_mark(h, ST_D3, st);
     launch_chain<false, -1, false, 1>(h, a, st);        // r3: (x+1, y-1)
     prof_mark(h, ST_H0, st);
-    launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
+    if (!h->hfused) launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
     prof_mark(h, ST_V2R, st);
     if (h->prm.mode == V3D_MODE_HH) {
         launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
@@ -714,7 +884,11 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         launch_chain<false, 1, true, 1>(h, a, st);      // (x-1, y+1)
     } else { prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st); }
     prof_mark(h, ST_H4_WTA, st);
-    launch_chain<true, -1, false, 2>(h, a, st);         // r4: (x+1, y), + WTA tail
+    if (h->hfused) {                                    // r0 + r4 + WTA tail in one launch
+        if (h->dpl == 4) hipLaunchKernelGGL(k_hfused<4>, dim3(v3d_cdiv(v3d_cdiv(H, 4) * n, 4)), dim3(256), 0, st, a, h->ckpt);
+        else hipLaunchKernelGGL(k_hfused<8>, dim3(v3d_cdiv(v3d_cdiv(H, 8) * n, 4)), dim3(256), 0, st, a, h->ckpt);
+    } else
+        launch_chain<true, -1, false, 2>(h, a, st);     // r4: (x+1, y), + WTA tail
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_LRCHECK, st);
     int16_t* raw = (last_stage == 2) ? out : h->raw;

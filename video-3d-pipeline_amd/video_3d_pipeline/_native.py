@@ -21,6 +21,7 @@ EXPORTS = (
     "v3d_median3x3_i16", "v3d_filter_speckles", "v3d_sbs_to_gray", "v3d_split_sbs", "v3d_disp_to_depth",
     "v3d_depth_to_u16", "v3d_guided_upscale_ws_bytes", "v3d_guided_upscale", "v3d_bgr_to_gray",
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
+    "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch",
     "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
 )
 
@@ -71,6 +72,8 @@ def lib():
         L.v3d_filter_speckles.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
         L.v3d_sbs_to_gray.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
         L.v3d_split_sbs.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+        L.v3d_sbs_to_gray_batch.argtypes = [vp, ci, ci, ci, ci, sz, ci, vp, vp, vp]
+        L.v3d_guided_upscale_batch.argtypes = [vp, ci, ci, sz, vp, ci, ci, sz, ci, ci, C.c_float, vp, vp, vp]
         L.v3d_disp_to_depth.argtypes = [vp, sz, vp, vp]
         L.v3d_depth_to_u16.argtypes = [vp, sz, vp, vp, vp]
         L.v3d_guided_upscale_ws_bytes.argtypes = [ci, ci]
@@ -218,6 +221,19 @@ def sbs_to_gray(sbs, unsqueeze=True):
     return L, R
 
 
+def sbs_to_gray_batch(sbs, unsqueeze=True, out=None):
+    """sbs: uint8 [N,H,W,3] -> (left, right) uint8 [N,H,outW], one launch"""
+    n, H, W, ch = sbs.shape
+    if W % 2:
+        raise ValueError("SBS frame width must be even")
+    ow = W if unsqueeze else W // 2
+    if out is None:
+        out = (torch.empty((n, H, ow), dtype=torch.uint8, device=sbs.device), torch.empty((n, H, ow), dtype=torch.uint8, device=sbs.device))
+    _check(lib().v3d_sbs_to_gray_batch(_dev(sbs, torch.uint8, "sbs"), n, W, H, W * 3, H * W * 3, int(bool(unsqueeze)),
+                                       _dev(out[0], torch.uint8, "L"), _dev(out[1], torch.uint8, "R"), _stream()), "v3d_sbs_to_gray_batch")
+    return out
+
+
 def split_sbs(sbs, unsqueeze=True):
     H, W, ch = sbs.shape
     if W % 2:
@@ -270,6 +286,28 @@ def guided_upscale(depth_lo, guide, r=8, eps=1e-3, out=None):
     _check(lib().v3d_guided_upscale(_dev(depth_lo, torch.float32, "depth_lo"), Wlo, Hlo, _dev(guide, torch.uint8, "guide"),
                                     Whi, Hhi, int(r), float(eps), _dev(out, torch.float32, "out"),
                                     _dev(ws, torch.uint8, "ws"), _stream()), "v3d_guided_upscale")
+    return out
+
+
+def guided_upscale_batch(depth_lo, guide, r=8, eps=1e-3, out=None):
+    """depth_lo f32 [N,Hlo,Wlo] (contiguous), guide u8 [N,Hhi,Whi] (frames may be strided) -> f32 [N,Hhi,Whi], one launch pair"""
+    n, Hlo, Wlo = depth_lo.shape
+    _, Hhi, Whi = guide.shape
+    if guide.stride(2) != 1 or guide.stride(1) != Whi:
+        raise NativeError("guide frames must be dense HxW images")
+    if out is None:
+        out = torch.empty((n, Hhi, Whi), dtype=torch.float32, device=guide.device)
+    key = (Whi, Hhi, n, guide.device.index)
+    ws = _gf_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib().v3d_guided_upscale_ws_bytes(Whi, Hhi)) * n, dtype=torch.uint8, device=guide.device)
+        _gf_ws[key] = ws
+    if guide.dtype != torch.uint8 or not guide.is_cuda:
+        raise NativeError("guide: expected a uint8 device tensor")
+    _check(lib().v3d_guided_upscale_batch(_dev(depth_lo, torch.float32, "depth_lo"), Wlo, Hlo, Hlo * Wlo,
+                                          C.c_void_p(guide.data_ptr()), Whi, Hhi, guide.stride(0), n, int(r), float(eps),
+                                          _dev(out, torch.float32, "out"), _dev(ws, torch.uint8, "ws"), _stream()),
+           "v3d_guided_upscale_batch")
     return out
 
 
