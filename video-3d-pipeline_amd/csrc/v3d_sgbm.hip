@@ -30,21 +30,35 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ i
                                                    int W, int H, int pitch, size_t frame_stride, int ft,
                                                    uint2* __restrict__ rec1, uint2* __restrict__ rec2)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
+    // one thread = one pixel; gradient/raw values are computed once and the x+-1 neighbours needed for the
+    // half-sample intervals come from LDS (block covers 254 output pixels + 1 halo each side)
+    __shared__ unsigned short sGR[2][256];
+    const int t = threadIdx.x;
+    const int x = blockIdx.x * 254 - 1 + t, y = blockIdx.y, f = blockIdx.z;
+    const int xc = min(max(x, 0), W - 1);
+    int g[2], r[2];
+#pragma unroll
     for (int im = 0; im < 2; im++) {
         const uint8_t* I = (im ? img2 : img1) + f * frame_stride;
         const uint8_t* r0 = I + (size_t)y * pitch;
         const uint8_t* ru = I + (size_t)(y > 0 ? y - 1 : y) * pitch;
         const uint8_t* rd = I + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
-        const int g = pf_grad(r0, ru, rd, x, W, ft), r = pf_raw(r0, x, W, ft);
-        int gl = g, gr = g, rl = r, rr = r;
-        if (x > 0) { gl = (g + pf_grad(r0, ru, rd, x - 1, W, ft)) >> 1; rl = (r + pf_raw(r0, x - 1, W, ft)) >> 1; }
-        if (x < W - 1) { gr = (g + pf_grad(r0, ru, rd, x + 1, W, ft)) >> 1; rr = (r + pf_raw(r0, x + 1, W, ft)) >> 1; }
-        const int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
-        const int q0 = min(min(rl, rr), r), q1 = max(max(rl, rr), r);
+        g[im] = pf_grad(r0, ru, rd, xc, W, ft);
+        r[im] = pf_raw(r0, xc, W, ft);
+        sGR[im][t] = (unsigned short)(g[im] | (r[im] << 8));
+    }
+    __syncthreads();
+    if (t == 0 || t == 255 || x >= W) return;
+#pragma unroll
+    for (int im = 0; im < 2; im++) {
+        const int lo = sGR[im][t - 1], hi = sGR[im][t + 1];
+        int gl = g[im], gr = g[im], rl = r[im], rr = r[im];
+        if (x > 0) { gl = (g[im] + (lo & 0xFF)) >> 1; rl = (r[im] + (lo >> 8)) >> 1; }
+        if (x < W - 1) { gr = (g[im] + (hi & 0xFF)) >> 1; rr = (r[im] + (hi >> 8)) >> 1; }
+        const int g0 = min(min(gl, gr), g[im]), g1 = max(max(gl, gr), g[im]);
+        const int q0 = min(min(rl, rr), r[im]), q1 = max(max(rl, rr), r[im]);
         uint2 rec;
-        rec.x = (uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24);
+        rec.x = (uint32_t)g[im] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r[im] << 24);
         rec.y = (uint32_t)q0 | ((uint32_t)q1 << 8);
         (im ? rec2 : rec1)[((size_t)f * H + y) * W + x] = rec;
     }
@@ -487,6 +501,8 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     uint32_t qdelta = P2pk;
     for (int blk = nblk - 1; blk >= 0; blk--) {
         const int x0 = blk * K;
+        // (prefetching the next block's C/S into a second register set was tried: 182 VGPRs halve the
+        //  occupancy and the kernel gets slower, 1.84 -> 2.07 ms per 8 frames; other waves cover the latency)
         Vec cvv[K], svv[K];
 #pragma unroll
         for (int j = 0; j < K; j++) {
@@ -611,48 +627,47 @@ __device__ __forceinline__ void ccl_union(int* L, int a, int b)
 }
 __device__ __forceinline__ bool ccl_conn(int a, int b, int newVal, int maxDiff) { return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
 
-// one block per image row
+// one block per image row; pixels are taken in chunks of 256 (thread t <-> pixel 256*j + t: coalesced),
+// the "latest run start at or before x" is an inclusive max-scan: DPP/shuffle inside a wave, 4 wave
+// totals through LDS, and a carry from chunk to chunk.
 __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff,
                                                   int* __restrict__ lab, int* __restrict__ rlen, int* __restrict__ csz)
 {
-    __shared__ int sLast[256];
-    const int y = blockIdx.x, t = threadIdx.x;
-    const size_t fo = (size_t)blockIdx.z * W * H;
-    const int16_t* row = img + fo + (size_t)y * W;
-    const int ppt = (W + 255) / 256;
-    const int xa = min(t * ppt, W), xb = min(xa + ppt, W);
-    // pass 1: last run start inside my chunk
-    int last = -1;
-    int prev = xa > 0 ? (int)row[xa - 1] : newVal;
-    for (int x = xa; x < xb; x++) {
-        const int v = row[x];
-        if (v != newVal && !ccl_conn(prev, v, newVal, maxDiff)) last = x;
-        prev = v;
-    }
-    sLast[t] = last;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {                 // inclusive max-scan
-        const int o = t >= off ? sLast[t - off] : -1;
-        __syncthreads();
-        sLast[t] = max(sLast[t], o);
-        __syncthreads();
-    }
-    int cur = t > 0 ? sLast[t - 1] : -1;                       // run start carried in from the left
-    // pass 2: labels, run lengths
-    prev = xa > 0 ? (int)row[xa - 1] : newVal;
-    for (int x = xa; x < xb; x++) {
-        const int v = row[x];
-        const size_t i = fo + (size_t)y * W + x;
-        csz[i] = 0;
-        if (v == newVal) { lab[i] = -1; rlen[i] = 0; }
-        else {
-            const bool start = !ccl_conn(prev, v, newVal, maxDiff);
-            if (start) cur = x; else rlen[i] = 0;
-            lab[i] = y * W + cur;
-            const int nxt = x + 1 < W ? (int)row[x + 1] : newVal;
-            if (!ccl_conn(v, nxt, newVal, maxDiff)) rlen[fo + (size_t)y * W + cur] = x - cur + 1;   // I am the run's last pixel
+    __shared__ int sWave[2][4];
+    const int y = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const size_t fo = (size_t)blockIdx.z * W * H + (size_t)y * W;
+    const int16_t* row = img + fo;
+    int carry = -1;
+    for (int x0 = 0, j = 0; x0 < W; x0 += 256, j++) {
+        const int x = x0 + t;
+        const bool in = x < W;
+        const int v = in ? (int)row[x] : newVal;
+        const int pv = (in && x > 0) ? (int)row[x - 1] : newVal;
+        const int nv = (in && x + 1 < W) ? (int)row[x + 1] : newVal;
+        const bool valid = v != newVal;
+        const bool start = valid && !ccl_conn(pv, v, newVal, maxDiff);
+        int m = start ? x : -1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {               // inclusive max-scan inside the wave
+            const int o = __shfl_up(m, off);
+            if (lane >= off) m = max(m, o);
         }
-        prev = v;
+        if (lane == 63) sWave[j & 1][wv] = m;
+        __syncthreads();
+        int pre = carry;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int tot = sWave[j & 1][w]; if (w < wv) pre = max(pre, tot); carry = max(carry, tot); }
+        const int cur = max(m, pre);                           // run start of pixel x (if valid)
+        if (in) {
+            const size_t i = fo + x;
+            csz[i] = 0;
+            if (!valid) { lab[i] = -1; rlen[i] = 0; }
+            else {
+                lab[i] = y * W + cur;
+                if (!start) rlen[i] = 0;
+                if (!ccl_conn(v, nv, newVal, maxDiff)) rlen[fo + cur] = x - cur + 1;     // I am the run's last pixel
+            }
+        }
     }
 }
 
@@ -853,7 +868,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     const int px = W * H;
 
     prof_mark(h, ST_PREFILTER, st);
-    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
+    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 254), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
     prof_mark(h, ST_COST, st);
     const bool vf = h->vfused && last_stage != 1;
     if (vf) hipLaunchKernelGGL(k_cost<true>, dim3(v3d_cdiv(W1, COST_OUT), 1, n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, H, h->P1, h->P2, h->C, h->S);
