@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (reference batch_size=8)")
+    ap.add_argument("--batch", type=int, default=15,
+                    help="frames per step per GPU (the reference's --batch-size; 15 = what one lock-step k_vdd launch holds co-resident)")
     ap.add_argument("--guide-exchange", choices=["broadcast", "scatter", "none"], default="broadcast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
 
     from video_3d_pipeline import _native as N, sharding, synthetic as syn
@@ -101,10 +103,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
+    if args.dist_backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)         # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        sharding.init_process_group("nccl")
+        sharding.init_process_group(args.dist_backend)
     N.lib()
     B = args.batch
 
@@ -211,6 +215,9 @@ def main():
         if stage_ms.get("chain_h0", 0.0) / max(calls, 1) < 0.02:     # both horizontal paths run inside the fused last launch
             sg["chain_h4_wta"] += sg["chain_h0"]
             sg["chain_h0"] = 0
+        if max(stage_ms.get("chain_d1", 0.0), stage_ms.get("chain_d3", 0.0)) / max(calls, 1) < 0.02:
+            sg["chain_v2"] += sg["chain_d1"] + sg["chain_d3"]        # k_vdd: all three top-down paths in the "chain_v2" slot
+            sg["chain_d1"] = sg["chain_d3"] = 0
         if stage_ms.get("chain_v2", 0.0) / max(calls, 1) < 0.02:     # vertical path rode inside k_cost
             sg["cost"] += sg["chain_v2"]
             sg["chain_v2"] = 0
@@ -226,8 +233,8 @@ def main():
         traffic = None                     # PMC counters cannot be read in-process: taken from the committed rocprofv3 --pmc passes
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-            if dom in tj and B == 8:
-                traffic = tj[dom]["traffic_bytes"]
+            if dom in tj:
+                traffic = int(tj[dom]["traffic_bytes"] * B / tj.get("_frames_per_launch", 8))
         except (OSError, KeyError, ValueError):
             pass
         sgbm_ms = sum(v["avg_ms"] for k, v in kernels.items() if not k.startswith("guided"))

@@ -76,6 +76,10 @@ int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t*
                            int n, int W, int H, int pitch, size_t frame_stride,
                            int16_t* disp16_out, void* stream);
 
+/* synchronises the device; returns the number of lock-step workgroups that timed out waiting for a
+   neighbour strip since create (0 = healthy; > 0 means results of that call are invalid) */
+int v3d_sgbm_sync_errors(v3d_sgbm* h);
+
 /* per-stage HIP-event timing on the caller's stream (what bench.py's `roofline` object reads):
    v3d_sgbm_profile(h, 1) resets and enables; run compute calls; synchronise the stream;
    v3d_sgbm_profile_read fills total_ms[stage] (n >= v3d_sgbm_profile_stage_count()) and returns the

@@ -166,6 +166,13 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
     const int cx = min(gx + RR, W - 1) - max(gx - RR, 0) + 1;
     const int nsteps = (yb - ya) + 2 * RR;
 
+    // bilinear source coordinates are separable: the x part is a per-thread constant, the y part per row
+    int bxa = 0, bxb = 0; double bwx = 0.0;
+    if (SWEEP == 1) {
+        const double fx = (gx + 0.5) * sx - 0.5, x0f = floor(fx);
+        bwx = fx - x0f;
+        bxa = min(max((int)x0f, 0), Wlo - 1); bxb = min(max((int)x0f + 1, 0), Wlo - 1);
+    }
     double r0[R], r1[R], v[NS];
 #pragma unroll
     for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; }
@@ -182,7 +189,12 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                 if (col_ok && e >= 0 && e < H) {
                     if (SWEEP == 1) {
                         n0 = (double)guide[(size_t)e * W + gx] / 255.0;
-                        n1 = gf_bilinear(depth_lo, Wlo, Hlo, sx, sy, gx, e);
+                        const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy), wy = fy - y0f;
+                        const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
+                        const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
+                        const double top = (double)ra[bxa] * (1.0 - bwx) + (double)ra[bxb] * bwx;
+                        const double bot = (double)rb[bxa] * (1.0 - bwx) + (double)rb[bxb] * bwx;
+                        n1 = top * (1.0 - wy) + bot * wy;
                     } else {
                         n0 = A[(size_t)e * W + gx];
                         n1 = B[(size_t)e * W + gx];

@@ -550,6 +550,162 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// a-5, the three top-down paths r1 = (x-1, y-1), r2 = (x, y-1), r3 = (x+1, y-1) in ONE pass over C
+// (SURVEY 8a-5's K_v): reads C once, writes S = L1 + L2 + L3 once -- 2 volumes instead of the
+// 7 that three k_chain launches move.
+//
+// The diagonals couple neighbouring columns row by row, so a column strip cannot run alone.  Here a
+// workgroup (1024 threads = 16 waves, 16 lanes x 4 disparities per pixel) owns a strip of 64 columns of
+// one frame and marches down the rows in LOCK-STEP with its two neighbour strips:
+//   * inside the strip the previous row's (L1, L3) state is exchanged through LDS (one barrier per row);
+//   * across strips the edge columns' state travels through global memory as 8-byte {data, tag} granules
+//     (relaxed agent-scope atomic stores / loads: sc1, served by L2, no fences -- MI355X_MICROARCH
+//     "handoff-1to1"), tag = (call sequence << 12) | (row + 1), 4-row ring per strip edge (stays in L2).
+// The coupling is bidirectional (strip k waits for k-1 AND k+1), so ALL strips of a launch must be
+// co-resident: the host sizes the launch from the occupancy query (with margin) and splits larger
+// batches; every spin is bounded and trips an error flag instead of hanging.
+// ------------------------------------------------------------------------------------------------
+#define VDD_PX 64                        // columns per strip
+#define VDD_RING 4
+#define VDD_GRAN 34                      // granules per edge per row: 32 data dwords + delta (+1 pad)
+#define VDD_SPIN_LIMIT (1 << 20)
+
+struct VddArgs {
+    const int16_t* C; int16_t* S;
+    int W1, H, nframes, nstrips;
+    int P1, P2;
+    uint32_t seq;
+    unsigned long long* gran;           // [frame][strip][2 dirs][VDD_RING][VDD_GRAN]
+    int* err;
+};
+
+__device__ __forceinline__ bool vdd_poll(const unsigned long long* g, uint32_t tag, uint32_t& v, int& budget)
+{
+    for (;;) {
+        const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) == tag) { v = (uint32_t)x; return true; }
+        if (--budget < 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void vdd_put(unsigned long long* g, uint32_t v, uint32_t tag)
+{
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void k_vdd(VddArgs a)
+{
+    // per-pixel exchanged state: 16 lanes x {L1 pair0, L1 pair1, L3 pair0, L3 pair1} + per pixel {delta1, delta3}
+    __shared__ uint4 sL[2][VDD_PX + 2][16];
+    __shared__ uint2 sDl[2][VDD_PX + 2];
+    constexpr int PF = 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = wv * 4 + (lane >> 4), dl = lane & 15;        // pixel inside the strip, disparity quad
+    const int frame = blockIdx.x / a.nstrips, strip = blockIdx.x - frame * a.nstrips;
+    const int W1 = a.W1, H = a.H;
+    const int x = strip * VDD_PX + px;
+    const bool colok = x < W1;
+    const int xc = min(x, W1 - 1);
+    const size_t fbase = (size_t)frame * H * W1 * V3D_D;
+    const int16_t* Cp = a.C + fbase + (size_t)xc * V3D_D + dl * 4;
+    int16_t* Sp = a.S + fbase + (size_t)xc * V3D_D + dl * 4;
+    const size_t rstride = (size_t)W1 * V3D_D;
+
+    const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
+    const bool has_left = strip > 0, has_right = strip + 1 < a.nstrips;
+    unsigned long long* gme = a.gran + ((size_t)(frame * a.nstrips + strip) * 2) * VDD_RING * VDD_GRAN;
+    const unsigned long long* gleft = a.gran + ((size_t)(frame * a.nstrips + strip - 1) * 2 + 1) * VDD_RING * VDD_GRAN;   // left neighbour, right-going
+    const unsigned long long* gright = a.gran + ((size_t)(frame * a.nstrips + strip + 1) * 2 + 0) * VDD_RING * VDD_GRAN;  // right neighbour, left-going
+    const bool poll_left = has_left && wv == 0 && lane < 16;       // fills halo slot 0 (state of column x0 - 1)
+    const bool poll_right = has_right && wv == 15 && lane >= 48;   // fills halo slot VDD_PX + 1
+    int budget = VDD_SPIN_LIMIT;
+    bool failed = false;
+
+    // row -1: every path starts from the out-of-image state (L = 0, delta = P2)
+    for (int i = tid; i < 2 * (VDD_PX + 2) * 16; i += 1024) (&sL[0][0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * (VDD_PX + 2); i += 1024) (&sDl[0][0])[i] = make_uint2(P2pk, P2pk);
+    uint32_t p2[2] = { 0u, 0u }, d2 = P2pk;
+
+    uint2 cq[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) cq[j] = *reinterpret_cast<const uint2*>(Cp + (size_t)min(j, H - 1) * rstride);
+    __syncthreads();
+
+    for (int y0 = 0; y0 < H; y0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const int y = y0 + j;
+            if (y < H) {                                           // uniform
+                const int prev = (y + 1) & 1, cur = y & 1;         // buffer holding row y-1 / receiving row y
+                // ---- 1. neighbours' edge state of row y-1 -> halo slots of buffer `prev` ----
+                if (y > 0) {
+                    const uint32_t tag = (a.seq << 12) | (uint32_t)y;          // row y-1 carries tag (y-1)+1
+                    const int slot = (y - 1) & (VDD_RING - 1);
+                    if (poll_left) {
+                        const unsigned long long* g = gleft + slot * VDD_GRAN;
+                        uint32_t v0 = 0, v1 = 0, vd = P2pk;
+                        bool ok = vdd_poll(g + 2 * dl, tag, v0, budget) && vdd_poll(g + 2 * dl + 1, tag, v1, budget);
+                        if (ok && dl == 0) ok = vdd_poll(g + 32, tag, vd, budget);
+                        if (!ok) { failed = true; budget = 0; }
+                        sL[prev][0][dl].x = v0; sL[prev][0][dl].y = v1;
+                        if (dl == 0) sDl[prev][0].x = vd;
+                    }
+                    if (poll_right) {
+                        const unsigned long long* g = gright + slot * VDD_GRAN;
+                        uint32_t v0 = 0, v1 = 0, vd = P2pk;
+                        bool ok = vdd_poll(g + 2 * dl, tag, v0, budget) && vdd_poll(g + 2 * dl + 1, tag, v1, budget);
+                        if (ok && dl == 0) ok = vdd_poll(g + 32, tag, vd, budget);
+                        if (!ok) { failed = true; budget = 0; }
+                        sL[prev][VDD_PX + 1][dl].z = v0; sL[prev][VDD_PX + 1][dl].w = v1;
+                        if (dl == 0) sDl[prev][VDD_PX + 1].y = vd;
+                    }
+                }
+                __syncthreads();
+                // ---- 2. the three recurrences for row y ----
+                const uint2 cvec = cq[j];
+                cq[j] = *reinterpret_cast<const uint2*>(Cp + (size_t)min(y + PF, H - 1) * rstride);
+                const uint32_t cv[2] = { cvec.x, cvec.y };
+                const uint4 ln = sL[prev][px][dl];                 // column x-1 (slot px = pixel px-1): its L1 is .x,.y
+                const uint4 rn = sL[prev][px + 2][dl];             // column x+1: its L3 is .z,.w
+                const uint32_t p1[2] = { ln.x, ln.y }, p3[2] = { rn.z, rn.w };
+                const uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
+                uint32_t L1[2], L2[2], L3[2];
+                uint32_t nd1 = chain_step<2, 16>(p1, d1, cv, L1, P1pk, P2pk, dl == 0, dl == 15);
+                uint32_t nd2 = chain_step<2, 16>(p2, d2, cv, L2, P1pk, P2pk, dl == 0, dl == 15);
+                uint32_t nd3 = chain_step<2, 16>(p3, d3, cv, L3, P1pk, P2pk, dl == 0, dl == 15);
+                if (!colok) { L1[0] = L1[1] = L3[0] = L3[1] = 0u; nd1 = nd3 = P2pk; }   // columns beyond the image: out-of-image state
+                p2[0] = L2[0]; p2[1] = L2[1]; d2 = nd2;
+                if (colok) {
+                    uint2 o;
+                    o.x = pk_add_sat(pk_add_sat(L1[0], L2[0]), L3[0]);
+                    o.y = pk_add_sat(pk_add_sat(L1[1], L2[1]), L3[1]);
+                    *reinterpret_cast<uint2*>(Sp + (size_t)y * rstride) = o;
+                }
+                // ---- 3. publish row y: LDS for the strip, granules for the neighbours ----
+                sL[cur][px + 1][dl] = make_uint4(L1[0], L1[1], L3[0], L3[1]);
+                if (dl == 0) sDl[cur][px + 1] = make_uint2(nd1, nd3);
+                if (y + 1 < H) {
+                    const uint32_t tag = (a.seq << 12) | (uint32_t)(y + 1);
+                    const int slot = y & (VDD_RING - 1);
+                    if (has_right && px == VDD_PX - 1) {           // my last column's L1 goes right
+                        unsigned long long* g = gme + (size_t)(1 * VDD_RING + slot) * VDD_GRAN;
+                        vdd_put(g + 2 * dl, L1[0], tag); vdd_put(g + 2 * dl + 1, L1[1], tag);
+                        if (dl == 0) vdd_put(g + 32, nd1, tag);
+                    }
+                    if (has_left && px == 0) {                      // my first column's L3 goes left
+                        unsigned long long* g = gme + (size_t)(0 * VDD_RING + slot) * VDD_GRAN;
+                        vdd_put(g + 2 * dl, L3[0], tag); vdd_put(g + 2 * dl + 1, L3[1], tag);
+                        if (dl == 0) vdd_put(g + 32, nd3, tag);
+                    }
+                }
+            }
+        }
+    }
+    if (failed) atomicAdd(a.err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // a-7: L-R consistency check; also writes the always-invalid columns x < 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
@@ -737,6 +893,11 @@ struct v3d_sgbm {
     int16_t *C, *S, *dispw, *raw, *med;
     uint32_t* d2key;
     uint32_t* ckpt;                             // k_hfused checkpoints
+    unsigned long long* gran;                   // k_vdd edge granules
+    int* vdd_err;
+    uint32_t vdd_seq;
+    int vdd_mode;                               // 0 off, 1 on
+    int vdd_max_frames;                         // co-residency bound per launch
     bool hfused, vfused;
     int32_t* labels;
     size_t bytes;
@@ -815,6 +976,24 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         rc |= ws_alloc(&h->ckpt, (c4 > c8 ? c4 : c8) * maxB, &h->bytes);
     }
     { const char* e2 = getenv("V3D_HFUSED"); h->hfused = !(e2 && atoi(e2) == 0); }
+    {
+        const int nstrips_max = v3d_cdiv(maxW - V3D_D, VDD_PX);
+        const size_t ng = (size_t)maxB * nstrips_max * 2 * VDD_RING * VDD_GRAN;
+        rc |= ws_alloc(&h->gran, ng, &h->bytes);
+        rc |= ws_alloc(&h->vdd_err, 64, &h->bytes);
+        if (!rc) { (void)hipMemset(h->gran, 0, ng * sizeof(unsigned long long)); (void)hipMemset(h->vdd_err, 0, 64 * sizeof(int)); }
+        h->vdd_seq = 1;
+        const char* e4 = getenv("V3D_VDD");
+        h->vdd_mode = (e4 && atoi(e4) == 0) ? 0 : 1;      // default on; V3D_VDD=0 falls back to three k_chain launches
+        // all strips of a launch must be resident together: bound frames per launch by the occupancy query, with margin
+        int bpm = 0, ncu = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpm, k_vdd, 1024, 0);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        if (bpm > 2) bpm = 2;
+        const int slots = bpm * ncu * 9 / 10;
+        h->vdd_max_frames = slots / nstrips_max;
+        if (h->vdd_max_frames < 1) h->vdd_mode = 0;
+    }
     { const char* e3 = getenv("V3D_VFUSED"); h->vfused = (e3 && atoi(e3) == 1); }   // measured: no gain at batch 8 (the unbanded kernel has too few waves); off
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
@@ -825,7 +1004,7 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt };
+    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt, h->gran, h->vdd_err };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
@@ -883,11 +1062,26 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     a.dispw = h->dispw; a.d2key = h->d2key;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
+    if (h->vdd_mode && !vf && H < 4095) {
+        // r1 + r2 + r3 in one lock-step pass (k_vdd); frames per launch bounded by co-residency
+        for (int f0 = 0; f0 < n; f0 += h->vdd_max_frames) {
+            VddArgs v;
+            const int nf = n - f0 < h->vdd_max_frames ? n - f0 : h->vdd_max_frames;
+            v.C = h->C + (size_t)f0 * H * W1 * V3D_D; v.S = h->S + (size_t)f0 * H * W1 * V3D_D;
+            v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, VDD_PX); v.P1 = h->P1; v.P2 = h->P2;
+            v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
+            v.gran = h->gran; v.err = h->vdd_err;
+            hipLaunchKernelGGL(k_vdd, dim3(v.nstrips * nf), dim3(1024), 0, st, v);
+        }
+        prof_mark(h, ST_D1, st);
+        prof_mark(h, ST_D3, st);
+    } else {
     if (!vf) launch_chain<false, 0, false, 0>(h, a, st);    // r2: (x, y-1) (else done inside k_cost)
     prof_mark(h, ST_D1, st);
     launch_chain<false, 1, false, 1>(h, a, st);         // r1: (x-1, y-1)
     prof_mark(h, ST_D3, st);
     launch_chain<false, -1, false, 1>(h, a, st);        // r3: (x+1, y-1)
+    }
     prof_mark(h, ST_H0, st);
     if (!h->hfused) launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
     prof_mark(h, ST_V2R, st);
@@ -927,6 +1121,17 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
 
 // ---- per-stage timing: enable (resets the counters), run any number of compute calls, synchronise the
 // stream, then read.  Events are recorded on the caller's stream between the stage launches. ----
+// synchronises the device and returns how many k_vdd workgroups gave up waiting for a neighbour (0 = healthy)
+extern "C" int v3d_sgbm_sync_errors(v3d_sgbm* h)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    int e = 0;
+    V3D_HIP_CHECK(hipSetDevice(h->device));
+    V3D_HIP_CHECK(hipDeviceSynchronize());
+    V3D_HIP_CHECK(hipMemcpy(&e, h->vdd_err, sizeof(int), hipMemcpyDeviceToHost));
+    return e;
+}
+
 extern "C" int v3d_sgbm_profile(v3d_sgbm* h, int enable)
 {
     if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }

@@ -22,7 +22,7 @@ EXPORTS = (
     "v3d_depth_to_u16", "v3d_guided_upscale_ws_bytes", "v3d_guided_upscale", "v3d_bgr_to_gray",
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
     "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch",
-    "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
+    "v3d_sgbm_sync_errors", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
 )
 
 
@@ -62,6 +62,7 @@ def lib():
         L.v3d_sgbm_workspace_bytes.restype = sz
         L.v3d_sgbm_compute.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
         L.v3d_sgbm_profile.argtypes = [vp, ci]
+        L.v3d_sgbm_sync_errors.argtypes = [vp]
         L.v3d_sgbm_profile_stage_name.argtypes = [ci]
         L.v3d_sgbm_profile_stage_name.restype = C.c_char_p
         L.v3d_sgbm_profile_read.argtypes = [vp, C.POINTER(C.c_double), ci]
@@ -158,6 +159,10 @@ class StereoSGBM:
                                                 n, W, H, W, H * W, _dev(o3, torch.int16, "out"), _stream()),
                    "v3d_sgbm_compute_batch")
         return out if batched else o3[0]
+
+    def sync_errors(self):
+        """device-synchronise; number of lock-step (k_vdd) workgroups that timed out on a neighbour (0 = healthy)"""
+        return int(lib().v3d_sgbm_sync_errors(self._h))
 
     def profile(self, enable=True):
         """per-stage HIP-event timing on the current stream: enable, run compute(), synchronize, read_profile()"""
@@ -323,4 +328,7 @@ def corr_lookup(fl, fr, flow, groups=4, pattern=0):
 
 
 def to_device(a, device="cuda"):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    a = np.ascontiguousarray(a)
+    if not a.flags.writeable:          # e.g. a memory-mapped clip: torch wants a writable buffer
+        a = a.copy()
+    return torch.from_numpy(a).to(device)

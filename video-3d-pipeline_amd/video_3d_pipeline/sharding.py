@@ -44,7 +44,9 @@ def init_process_group(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend=backend)
 
 
 def barrier():
