@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=15,
-                    help="frames per step per GPU (the reference's --batch-size; 15 = what one lock-step k_vdd launch holds co-resident)")
+    ap.add_argument("--batch", type=int, default=30,
+                    help="frames per step per GPU (the reference's --batch-size; 30 = what one lock-step k_vdd launch holds co-resident)")
     ap.add_argument("--guide-exchange", choices=["broadcast", "scatter", "none"], default="broadcast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")

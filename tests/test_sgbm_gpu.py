@@ -104,6 +104,7 @@ def test_chain_lane_mappings_agree(native, oracle, monkeypatch):
     W, H = 230, 90
     L, R = textured_pair(W, H, seed=31)
     want = oracle.sgbm_compute(L, R)
+    monkeypatch.setenv("V3D_VDD", "0")                      # the per-direction k_chain launches
     for dpl in ("8", "4"):
         monkeypatch.setenv("V3D_CHAIN_DPL", dpl)
         m = native.StereoSGBM(max_width=W, max_height=H)
@@ -169,11 +170,13 @@ def test_full_size_1080p_properties(native, oracle, matcher):
     assert not mismatch_report(d, want, "1080p disp16"), mismatch_report(d, want, "1080p disp16")
 
 
-@pytest.mark.parametrize("W,H,n", [(160, 96, 1), (203, 77, 2), (320, 180, 3), (64 + 128, 40, 1), (64 + 129, 33, 2)])
-def test_lockstep_top_down_kernel(native, oracle, monkeypatch, W, H, n):
+@pytest.mark.parametrize("dpl", ["4", "8"])
+@pytest.mark.parametrize("W,H,n", [(160, 96, 1), (203, 77, 2), (320, 180, 3), (64 + 128, 40, 1), (64 + 129, 33, 2), (64 + 256, 21, 1)])
+def test_lockstep_top_down_kernel(native, oracle, monkeypatch, W, H, n, dpl):
     """V3D_VDD=1: r1 + r2 + r3 in one lock-step pass (k_vdd) instead of three k_chain launches.
     Covers strips that end mid-image, exact multiples of the strip width, multi-frame launches."""
     monkeypatch.setenv("V3D_VDD", "1")
+    monkeypatch.setenv("V3D_VDD_DPL", dpl)
     pairs = [textured_pair(W, H, seed=50 + i) for i in range(n)]
     m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n)
     Ls = _dev(native, np.stack([p[0] for p in pairs]))

@@ -69,4 +69,11 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
     // lanes whose source is outside the row keep `old` (bound_ctrl = 0)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
 }
+// butterfly exchange (every lane has a valid source): bound_ctrl form, which the DPP-combine pass can fold into
+// the consuming VOP2 instruction (v_min_u32_dpp ...)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_xchg(uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xF, 0xF, true);
+}
 #endif
