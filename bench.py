@@ -263,6 +263,7 @@ def main():
                                             "achieved": gf["guided_sweep1+2"] / (gfa / B * 1e-3) / 1e9},
                          "stage_ms_per_launch": {k: round(v["avg_ms"], 4) for k, v in kernels.items()}},
         }
+        res["lockstep_timeouts"] = matcher.sync_errors()            # must be 0: k_vdd's bounded neighbour waits never tripped
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(base_sbs[0], base_guide[0])
         else:

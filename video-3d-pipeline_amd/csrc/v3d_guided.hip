@@ -151,12 +151,15 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                                              double* __restrict__ A, double* __restrict__ B, float* __restrict__ out,
                                              size_t depth_stride, size_t guide_stride)
 {
-    constexpr int R = 2 * RR + 1, NS = SWEEP == 1 ? 4 : 2;
+    constexpr int R = 2 * RR + 1;
+    // sweep 1 sums {g, g*g} as exact int32 (the guide is 8-bit: sum(I) = sum(g)/255, sum(I*I) = sum(g*g)/255^2) and
+    // {p, g*p} in f64; sweep 2 sums {a, b} in f64
+    __shared__ double sVd[2][2][256];
+    __shared__ int sVi[2][2][256];
     {   // frame of the batch
         const size_t f = blockIdx.z, n4 = (size_t)W * H;
         depth_lo += f * depth_stride; guide += f * guide_stride; A += f * 2 * n4; B += f * 2 * n4; out += f * n4;
     }
-    __shared__ double sV[2][NS][256];
     const int tid = threadIdx.x;
     const int gx = blockIdx.x * (256 - 2 * RR) - RR + tid;          // this thread's image column
     const int ya = blockIdx.y * band_h, yb = min(ya + band_h, H);
@@ -173,11 +176,10 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
         bwx = fx - x0f;
         bxa = min(max((int)x0f, 0), Wlo - 1); bxb = min(max((int)x0f + 1, 0), Wlo - 1);
     }
-    double r0[R], r1[R], v[NS];
+    double r0[R], r1[R], v0 = 0.0, v1 = 0.0;     // sweep 1: r1 = p ring, v0 = sum p, v1 = sum g*p ; sweep 2: a, b rings and sums
+    int rg[R], vg = 0, vgg = 0;                   // sweep 1: g ring, sum g, sum g*g
 #pragma unroll
-    for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; }
-#pragma unroll
-    for (int q = 0; q < NS; q++) v[q] = 0.0;
+    for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; rg[j] = 0; }
 
     for (int t0 = 0; t0 < nsteps; t0 += R) {
 #pragma unroll
@@ -185,50 +187,54 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
             const int t = t0 + j;
             if (t < nsteps) {                                        // uniform
                 const int e = ya - RR + t;                           // row entering the window
-                double n0 = 0.0, n1 = 0.0;
-                if (col_ok && e >= 0 && e < H) {
-                    if (SWEEP == 1) {
-                        n0 = (double)guide[(size_t)e * W + gx] * (1.0 / 255.0);
+                const bool in = col_ok && e >= 0 && e < H;
+                if (SWEEP == 1) {
+                    int gn = 0; double pn = 0.0;
+                    if (in) {
+                        gn = guide[(size_t)e * W + gx];
                         const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy), wy = fy - y0f;
                         const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
                         const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
                         const double top = (double)ra[bxa] * (1.0 - bwx) + (double)ra[bxb] * bwx;
                         const double bot = (double)rb[bxa] * (1.0 - bwx) + (double)rb[bxb] * bwx;
-                        n1 = top * (1.0 - wy) + bot * wy;
-                    } else {
-                        n0 = A[(size_t)e * W + gx];
-                        n1 = B[(size_t)e * W + gx];
+                        pn = top * (1.0 - wy) + bot * wy;
                     }
+                    const int go = rg[j]; const double po = r1[j];   // row e - R leaves (zeros during warm-up)
+                    rg[j] = gn; r1[j] = pn;
+                    vg += gn - go; vgg += gn * gn - go * go;
+                    v0 += pn - po; v1 += (double)gn * pn - (double)go * po;
+                } else {
+                    double n0 = 0.0, n1 = 0.0;
+                    if (in) { n0 = A[(size_t)e * W + gx]; n1 = B[(size_t)e * W + gx]; }
+                    const double o0 = r0[j], o1 = r1[j];
+                    r0[j] = n0; r1[j] = n1;
+                    v0 += n0 - o0; v1 += n1 - o1;
                 }
-                const double o0 = r0[j], o1 = r1[j];                 // row e - R leaves (zeros during warm-up)
-                r0[j] = n0; r1[j] = n1;
-                v[0] += n0 - o0; v[1] += n1 - o1;
-                if (SWEEP == 1) { v[2] += n0 * n0 - o0 * o0; v[3] += n0 * n1 - o0 * o1; }
                 const int y = e - RR;                                // output row whose window is now complete
                 if (y >= ya) {                                       // uniform
                     const int buf = t & 1;
-#pragma unroll
-                    for (int q = 0; q < NS; q++) sV[buf][q][tid] = v[q];
+                    sVd[buf][0][tid] = v0; sVd[buf][1][tid] = v1;
+                    if (SWEEP == 1) { sVi[buf][0][tid] = vg; sVi[buf][1][tid] = vgg; }
                     __syncthreads();
                     if (out_col) {
-                        double s[NS];
+                        double s0 = 0.0, s1 = 0.0; int sg = 0, sgg = 0;
 #pragma unroll
-                        for (int q = 0; q < NS; q++) s[q] = 0.0;
-#pragma unroll
-                        for (int k = -RR; k <= RR; k++)
-#pragma unroll
-                            for (int q = 0; q < NS; q++) s[q] += sV[buf][q][tid + k];
+                        for (int k = -RR; k <= RR; k++) {
+                            s0 += sVd[buf][0][tid + k]; s1 += sVd[buf][1][tid + k];
+                            if (SWEEP == 1) { sg += sVi[buf][0][tid + k]; sgg += sVi[buf][1][tid + k]; }
+                        }
                         const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
                         const double inv = 1.0 / (double)(cx * cy);   // one f64 division instead of four (1 ulp, far inside 1e-3)
                         if (SWEEP == 1) {
-                            const double mI = s[0] * inv, mp = s[1] * inv, mII = s[2] * inv, mIp = s[3] * inv;
+                            const double mI = (double)sg * (inv * (1.0 / 255.0)), mp = s0 * inv;
+                            const double mII = (double)sgg * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
                             const double var = mII - mI * mI, cov = mIp - mI * mp;
                             const double a = cov / (var + eps);
                             A[(size_t)y * W + gx] = a;
                             B[(size_t)y * W + gx] = mp - a * mI;
                         } else {
                             const double I = (double)guide[(size_t)y * W + gx] * (1.0 / 255.0);
-                            out[(size_t)y * W + gx] = (float)((s[0] * inv) * I + (s[1] * inv));
+                            out[(size_t)y * W + gx] = (float)((s0 * inv) * I + (s1 * inv));
                         }
                     }
                 }
@@ -241,11 +247,14 @@ template <int RR>
 static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        double* A, double* B, float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
-    const char* e = getenv("V3D_GF_BAND");
-    const int band_h = e ? atoi(e) : 48;
-    const dim3 grid(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band_h), n);
-    hipLaunchKernelGGL((k_gfm<1, RR>), grid, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band_h, A, B, out, depth_stride, guide_stride);
-    hipLaunchKernelGGL((k_gfm<2, RR>), grid, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band_h, A, B, out, depth_stride, guide_stride);
+    // band heights: sweep 1 is f64-compute bound (smaller bands = more workgroups), sweep 2 is bound by its halo'd
+    // re-reads of the f64 a/b planes (taller bands = less halo)
+    const char* e1 = getenv("V3D_GF_BAND1");
+    const char* e2 = getenv("V3D_GF_BAND2");
+    const int band1 = e1 ? atoi(e1) : 40, band2 = e2 ? atoi(e2) : 270;
+    const dim3 grid1(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band1), n), grid2(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band2), n);
+    hipLaunchKernelGGL((k_gfm<1, RR>), grid1, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band1, A, B, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gfm<2, RR>), grid2, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band2, A, B, out, depth_stride, guide_stride);
 }
 
 extern "C" size_t v3d_guided_upscale_ws_bytes(int W, int H)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
                                                    LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR,
                                                    size_t in_stride)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t sRow[(256 + 8) * 3 + 8];
+    __shared__ __attribute__((aligned(4))) uint8_t sRow[(256 + 8) * 3 + 16];
     const int hw = W >> 1, ow = unsqueeze ? W : hw;
     const int t = threadIdx.x;
     const int xb = blockIdx.x * 256, x = xb + t, y = blockIdx.y, eye = blockIdx.z & 1, f = blockIdx.z >> 1;
@@ -53,9 +53,20 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
     // source pixels [s0, s0 + ns) of the half row are needed by this block
     const int s0 = unsqueeze ? (xb >> 1) - 4 : xb;
     const int ns = unsqueeze ? 128 + 8 : 256;
-    for (int i = t; i < ns * 3; i += 256) {
-        const int px = i / 3, c = i - px * 3;
-        sRow[i] = row[min(max(s0 + px, 0), hw - 1) * 3 + c];                // replicate border
+    int soff = 0;                                               // byte offset of pixel s0 inside sRow
+    if (s0 >= 0 && (s0 + ns < hw || (eye == 0 && s0 + ns <= hw))) {
+        // interior block: aligned dword loads of the span; the <= 3 bytes of over-read stay inside this image row
+        // (edge blocks take the clamped byte path)
+        const uintptr_t a = reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3);
+        const uint32_t* a0 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+        soff = (int)(a & 3);
+        const int nd = (soff + ns * 3 + 3) >> 2;
+        for (int i = t; i < nd; i += 256) reinterpret_cast<uint32_t*>(sRow)[i] = a0[i];
+    } else {
+        for (int i = t; i < ns * 3; i += 256) {
+            const int px = i / 3, c = i - px * 3;
+            sRow[i] = row[min(max(s0 + px, 0), hw - 1) * 3 + c];            // replicate border
+        }
     }
     __syncthreads();
     if (x >= ow) return;
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
         int ab = 0, ag = 0, ar = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint8_t* p = sRow + (sx + k - 3 - s0) * 3;
+            const uint8_t* p = sRow + soff + (sx + k - 3 - s0) * 3;
             const int tp = taps.t[odd][k];
             ab += p[0] * tp; ag += p[1] * tp; ar += p[2] * tp;
         }
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
         g = min(max((int)(((long long)ag * 2048 + (1 << 21)) >> 22), 0), 255);
         r = min(max((int)(((long long)ar * 2048 + (1 << 21)) >> 22), 0), 255);
     } else {
-        const uint8_t* p = sRow + t * 3;
+        const uint8_t* p = sRow + soff + t * 3;
         b = p[0]; g = p[1]; r = p[2];
     }
     uint8_t* out = eye ? outR : outL;

@@ -51,6 +51,15 @@ class HipStereoBackend:
             self._geom = (W, H, n)
         return self._matcher
 
+    @staticmethod
+    def _check_lockstep(matcher):
+        """the lock-step SGM kernel needs all its workgroups resident at once; if another process is hogging the
+        GPU its bounded spins give up and it raises a flag -- fail loudly rather than return a wrong disparity"""
+        n = matcher.sync_errors()
+        if n:
+            raise RuntimeError(f"SGM lock-step kernel timed out waiting for neighbour strips ({n} workgroups): the GPU is "
+                               "over-subscribed; re-run with V3D_VDD=0 or without other jobs on this device")
+
     def split_sbs(self, sbs_frame: np.ndarray, unsqueeze: bool):
         d = self.native.to_device(sbs_frame, self.device)
         L, R = self.native.split_sbs(d, unsqueeze)
@@ -66,9 +75,11 @@ class HipStereoBackend:
         for i, (l, r) in enumerate(pairs):
             lg[i] = nat.bgr_to_gray(nat.to_device(l, self.device))
             rg[i] = nat.bgr_to_gray(nat.to_device(r, self.device))
-        disp = self._get_matcher(W, H, n).compute(lg, rg)
+        matcher = self._get_matcher(W, H, n)
+        disp = matcher.compute(lg, rg)
         depth = nat.disp_to_depth(disp)
         out = depth.cpu().numpy()
+        self._check_lockstep(matcher)
         return [out[i] for i in range(n)]
 
     def sbs_to_disparity(self, frames: List[np.ndarray], unsqueeze: bool):
@@ -82,8 +93,11 @@ class HipStereoBackend:
         for i, f in enumerate(frames):
             l, r = nat.sbs_to_gray(nat.to_device(f, self.device), unsqueeze)
             lg[i], rg[i] = l, r
-        disp = self._get_matcher(ow, H, n).compute(lg, rg)
-        return nat.disp_to_depth(disp)
+        matcher = self._get_matcher(ow, H, n)
+        disp = matcher.compute(lg, rg)
+        depth = nat.disp_to_depth(disp)
+        self._check_lockstep(matcher)
+        return depth
 
     def normalise_u16(self, depth) -> np.ndarray:
         nat = self.native
