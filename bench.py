@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=30,
                     help="frames per step per GPU (the reference's --batch-size; 30 = what one lock-step k_vdd launch holds co-resident)")
-    ap.add_argument("--guide-exchange", choices=["broadcast", "scatter", "none"], default="broadcast")
+    ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="auto",
+                    help="how rank 0 hands out the 4K guide rounds: broadcast the whole round (north_star), scatter each rank's "
+                         "frames (world x fewer bytes), or auto = broadcast if it hides behind one compute step, else scatter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
@@ -119,12 +121,17 @@ def main():
     guide_own = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)
     Hh, Wh = H * SCALE, W * SCALE
     # guide rounds: round j holds the guide frames of global frames j*world .. j*world+world-1 (rank r owns slot r)
+    mode = {"v": args.guide_exchange}
+    exch_info = {}
     if world > 1 and args.guide_exchange != "none":
         rounds_src = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)      # [B,Hh,Wh]
         rounds_src = rounds_src[:, None].expand(B, world, Hh, Wh).contiguous() if rank == 0 else None
-        guide_buf = [torch.empty((B, world, Hh, Wh), dtype=torch.uint8, device=dev) if args.guide_exchange == "broadcast"
-                     else torch.empty((B, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
+        guide_buf = None
+
+        def alloc_bufs():
+            return [torch.empty((B, world, Hh, Wh), dtype=torch.uint8, device=dev) if mode["v"] == "broadcast"
+                    else torch.empty((B, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(2)]
     else:
         rounds_src, guide_buf, side = None, None, None
 
@@ -140,7 +147,7 @@ def main():
         if guide_buf is None:
             return None
         with torch.cuda.stream(side):
-            if args.guide_exchange == "broadcast":
+            if mode["v"] == "broadcast":
                 if rank == 0:
                     guide_buf[slot].copy_(rounds_src)
                 dist.broadcast(guide_buf[slot], src=0)
@@ -154,7 +161,7 @@ def main():
     def my_guides(slot):
         if guide_buf is None:
             return guide_own
-        return guide_buf[slot][:, rank] if args.guide_exchange == "broadcast" else guide_buf[slot]
+        return guide_buf[slot][:, rank] if mode["v"] == "broadcast" else guide_buf[slot]
 
     gf_ev = []
 
@@ -190,6 +197,25 @@ def main():
             evs.append(e)
         return evs
 
+    if world > 1 and args.guide_exchange != "none":
+        if args.guide_exchange == "auto":
+            # time one compute step and one full-round broadcast; keep the broadcast only if it hides behind the step
+            mode["v"] = "broadcast"
+            guide_buf = alloc_bufs()
+            step(guide_own, False); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter(); step(guide_own, False); torch.cuda.synchronize(); t_step = time.perf_counter() - t0
+            exchange(0); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter(); exchange(0); torch.cuda.synchronize(); dist.barrier(); t_bc = time.perf_counter() - t0
+            tt = torch.tensor([t_step, t_bc], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_step, t_bc = float(tt[0]), float(tt[1])
+            exch_info = {"step_ms": t_step * 1e3, "broadcast_ms": t_bc * 1e3}
+            if t_bc > 0.8 * t_step:
+                mode["v"] = "scatter"
+                guide_buf = None
+                torch.cuda.empty_cache()
+        if guide_buf is None:
+            guide_buf = alloc_bufs()
     run(args.warmup, False)
     torch.cuda.synchronize()
     matcher.profile(True)
@@ -250,7 +276,7 @@ def main():
             "config": {"workload": "configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth",
                        "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_SGBM (5 paths)",
                        "guided_radius": 8, "guided_eps": 1e-3, "parallelism": f"frames round-robin over {world} GPU(s)",
-                       "guide_exchange": args.guide_exchange if world > 1 else "local"},
+                       "guide_exchange": (mode["v"] if world > 1 else "local"), "guide_exchange_probe": exch_info},
             "p50_ms_per_frame": statistics.median(step_ms) / B,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
