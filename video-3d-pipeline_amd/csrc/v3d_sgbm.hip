@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
     // aligned dword: no byte extraction in the hot loop.  Left-image values are stored pre-broadcast.
     __shared__ __attribute__((aligned(8))) unsigned short sRV[2][2][6][COST_NREC + 4];
     __shared__ __attribute__((aligned(8))) uint32_t sUL[2][COST_COLS][6];
-    __shared__ uint32_t sPix[2][COST_COLS][16];
+    __shared__ uint2 sPix[2][COST_COLS][16];                    // BT cost of 4 disparities as two packed u16 pairs
 
     const int tid = threadIdx.x, col = tid >> 4, dq = tid & 15;
     const int xr0 = blockIdx.x * COST_OUT;
@@ -147,12 +147,18 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
     uint2 n1 = fetch(1), n2 = fetch(2), n3 = fetch(3);
     __syncthreads();
 
-    uint32_t hE0 = 0, hE1 = 0, hE2 = 0, hE3 = 0, hO0 = 0, hO1 = 0, hO2 = 0, hO3 = 0;
+    uint32_t ring[5][2], vs01 = 0u, vs23 = 0u;                  // last five rows' horizontal sums + their running sum
+#pragma unroll
+    for (int i = 0; i < 5; i++) ring[i][0] = ring[i][1] = 0u;
     const uint32_t P2pk = pk_bcast(P2), P1pk = pk_bcast(P1);
     uint32_t vp[2] = { 0u, 0u }, vdelta = P2pk;                 // vertical path state (FUSE_V)
     int16_t* Sf = FUSE_V ? S + (size_t)f * H * W1 * V3D_D : nullptr;
 
-    for (int k = 0; k < nrows; k++) {
+    for (int k5 = 0; k5 < nrows; k5 += 5) {
+#pragma unroll
+      for (int slot = 0; slot < 5; slot++) {                    // the ring slot is a compile-time index: no register shifts
+        const int k = k5 + slot;
+        if (k >= nrows) break;                                  // uniform
         const int buf = k & 1;
         const uint2 n4 = fetch(k + 4);
 
@@ -169,25 +175,23 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
         const uint32_t g23 = bt_pair(U[0], U[1], U[2], V23[0], V23[1], V23[2]);
         const uint32_t r23 = bt_pair(U[3], U[4], U[5], V23[3], V23[4], V23[5]);
         const uint32_t p01 = g01 + pk_shr_u(r01, 2), p23 = g23 + pk_shr_u(r23, 2);      // each half <= 93
-        sPix[buf][col][dq] = __builtin_amdgcn_perm(p23, p01, 0x06040200u);               // bytes d0, d1, d2, d3
+        sPix[buf][col][dq] = make_uint2(p01, p23);
 
         if (k + 1 < nrows && ld_src) stage(buf ^ 1, n1);
         n1 = n2; n2 = n3; n3 = n4;
         __syncthreads();
 
-        // ---- 5-tap horizontal sum (bytes d0..d3 -> (d0,d2) / (d1,d3) u16 pairs), 5-row vertical sum ----
+        // ---- 5-tap horizontal sum on packed u16 pairs, 5-row vertical running sum ----
         if (out_col) {
-            const uint32_t w0 = sPix[buf][col - 2][dq], w1 = sPix[buf][col - 1][dq], w2 = sPix[buf][col][dq],
-                           w3 = sPix[buf][col + 1][dq], w4 = sPix[buf][col + 2][dq];
-            const uint32_t sa = w0 + w1, sb = w2 + w3;                                   // bytes <= 186: no carry
-            const uint32_t hE = (sa & 0x00FF00FFu) + (sb & 0x00FF00FFu) + (w4 & 0x00FF00FFu);
-            const uint32_t hO = ((sa >> 8) & 0x00FF00FFu) + ((sb >> 8) & 0x00FF00FFu) + ((w4 >> 8) & 0x00FF00FFu);
+            const uint2 w0 = sPix[buf][col - 2][dq], w1 = sPix[buf][col - 1][dq], w2 = sPix[buf][col][dq],
+                        w3 = sPix[buf][col + 1][dq], w4 = sPix[buf][col + 2][dq];
+            const uint32_t h01 = w0.x + w1.x + w2.x + w3.x + w4.x;                       // halves <= 5 * 189: no carry
+            const uint32_t h23 = w0.y + w1.y + w2.y + w3.y + w4.y;
+            vs01 += h01 - ring[slot][0]; vs23 += h23 - ring[slot][1];                    // add row k, drop row k - 5
+            ring[slot][0] = h01; ring[slot][1] = h23;
             if (k >= 4) {
-                const uint32_t cE = hE + hE0 + hE1 + hE2 + hE3 + P2pk;                   // (d0, d2)
-                const uint32_t cO = hO + hO0 + hO1 + hO2 + hO3 + P2pk;                   // (d1, d3)
                 uint2 o;
-                o.x = (cE & 0xFFFFu) | (cO << 16);
-                o.y = (cE >> 16) | (cO & 0xFFFF0000u);
+                o.x = vs01 + P2pk; o.y = vs23 + P2pk;
                 const int y = ys + k - 4;
                 const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq;
                 *reinterpret_cast<uint2*>(Cf + off) = o;
@@ -199,9 +203,8 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
                     *reinterpret_cast<uint2*>(Sf + off) = make_uint2(L[0], L[1]);
                 }
             }
-            hE3 = hE2; hE2 = hE1; hE1 = hE0; hE0 = hE;
-            hO3 = hO2; hO2 = hO1; hO1 = hO0; hO0 = hO;
         }
+      }
     }
 }
 
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
 template <int DPL>
 __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restrict__ ckpt)
 {
-    constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW, PF = 4;
+    constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW;
     typedef typename VecT<DPL>::type Vec;
     __shared__ __attribute__((aligned(16))) unsigned char sS[4 * 64 * WTA_ROWB];
 
@@ -474,16 +477,15 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
         for (int i = 0; i < NP; i++) p[i] = 0;
         uint32_t delta = P2pk;
         const int xend = (nblk - 1) * K;                       // the last block is recomputed in phase 2 anyway
-        Vec cq[PF];
-#pragma unroll
-        for (int j = 0; j < PF; j++) cq[j] = *reinterpret_cast<const Vec*>(Crow + (size_t)min(j, W1 - 1) * V3D_D);
         for (int xb = 0; xb < xend; xb += K) {
+            // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
+            Vec cb[K];
+#pragma unroll
+            for (int jj = 0; jj < K; jj++) cb[jj] = *reinterpret_cast<const Vec*>(Crow + (size_t)(xb + jj) * V3D_D);
 #pragma unroll
             for (int jj = 0; jj < K; jj++) {
-                const int j = jj % PF, x = xb + jj;
                 uint32_t cv[NP], L[NP];
-                vec_unpack<NP>(cq[j], cv);
-                cq[j] = *reinterpret_cast<const Vec*>(Crow + (size_t)min(x + PF, W1 - 1) * V3D_D);
+                vec_unpack<NP>(cb[jj], cv);
                 delta = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
 #pragma unroll
                 for (int i = 0; i < NP; i++) p[i] = L[i];
