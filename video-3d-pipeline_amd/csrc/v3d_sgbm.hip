@@ -582,11 +582,26 @@ struct VddArgs {
     int* err;
 };
 
-__device__ __forceinline__ bool vdd_poll(const unsigned long long* g, uint32_t tag, uint32_t& v, int& budget)
+// wait for N data granules (+ the delta granule if want_d) of one row: all loads of a poll round go out together
+// (one L2 round trip per round, not one per granule); bounded by `budget`
+template <int N>
+__device__ __forceinline__ bool vdd_poll_n(const unsigned long long* g, const unsigned long long* gd, bool want_d,
+                                           uint32_t tag, uint32_t (&v)[N], uint32_t& vd, int& budget)
 {
     for (;;) {
-        const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(x >> 32) == tag) { v = (uint32_t)x; return true; }
+        unsigned long long x[N], xd = (unsigned long long)tag << 32;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (want_d) xd = __hip_atomic_load(gd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = (uint32_t)(xd >> 32) == tag;
+#pragma unroll
+        for (int i = 0; i < N; i++) ok = ok && ((uint32_t)(x[i] >> 32) == tag);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < N; i++) v[i] = (uint32_t)x[i];
+            if (want_d) vd = (uint32_t)xd;
+            return true;
+        }
         if (--budget < 0) return false;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -600,7 +615,7 @@ template <int DPL>
 __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD = two workgroups per CU: the second hides the hand-off latency
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, PXS = 16 * PPW;   // PXS = columns per strip (64 / 128)
-    constexpr int PF = 4;
+    constexpr int PF = DPL == 8 ? 1 : 4;         // C prefetch depth in rows (the 64-VGPR budget of two workgroups per CU binds at DPL = 8)
     typedef typename VecT<DPL>::type Vec;
     // per-pixel exchanged state: LPP lanes x {L1 (NP dwords), L3 (NP dwords)} + per pixel {delta1, delta3}
     __shared__ Vec sL1[2][PXS + 2][LPP];
@@ -655,63 +670,41 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
             const int y = y0 + j;
             if (y < H) {                                           // uniform
                 const int prev = (y + 1) & 1, cur = y & 1;         // buffer holding row y-1 / receiving row y
-                // ---- 1. neighbours' edge state of row y-1 -> halo slots of buffer `prev` ----
-                if (y > 0) {
-                    const uint32_t tag = (a.seq << 12) | (uint32_t)y;          // row y-1 carries tag (y-1)+1
-                    const int slot = (y - 1) & (VDD_RING - 1);
-                    if (edge_l) if (lane_l) {                       // fills halo slot 0 (state of column x0 - 1)
-                        const unsigned long long* g = gleft + slot * VDD_GRAN;
-                        uint32_t v[NP], vd = P2pk;
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < NP; i++) { v[i] = 0u; ok = ok && vdd_poll(g + NP * dl + i, tag, v[i], budget); }
-                        if (ok && dl == 0) ok = vdd_poll(g + 32, tag, vd, budget);
-                        if (!ok) { failed = true; budget = 0; }
-                        sL1[prev][0][dl] = Packer<NP>::go(v);
-                        if (dl == 0) sDl[prev][0].x = vd;
-                    }
-                    if (edge_r) if (lane_r) {                       // fills halo slot PXS + 1
-                        const unsigned long long* g = gright + slot * VDD_GRAN;
-                        uint32_t v[NP], vd = P2pk;
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < NP; i++) { v[i] = 0u; ok = ok && vdd_poll(g + NP * dl + i, tag, v[i], budget); }
-                        if (ok && dl == 0) ok = vdd_poll(g + 32, tag, vd, budget);
-                        if (!ok) { failed = true; budget = 0; }
-                        sL3[prev][PXS + 1][dl] = Packer<NP>::go(v);
-                        if (dl == 0) sDl[prev][PXS + 1].y = vd;
-                    }
-                }
-                __syncthreads();
-                // ---- 2. the three recurrences for row y ----
+                __syncthreads();                                   // row y-1 of the whole strip is in buffer `prev`
+                // ---- 1. predecessors: strip neighbours from LDS; the two edge pixels take theirs from the neighbour
+                //         strips' granules, polled AFTER the barrier so the other 14 waves compute meanwhile ----
                 uint32_t cv[NP], p1[NP], p3[NP];
                 vec_unpack<NP>(cq[j], cv);
                 cq[j] = *reinterpret_cast<const Vec*>(Cp + (size_t)min(y + PF, H - 1) * rstride);
                 vec_unpack<NP>(sL1[prev][px][dl], p1);             // column x-1 (slot px holds pixel px-1)
                 vec_unpack<NP>(sL3[prev][px + 2][dl], p3);         // column x+1
-                const uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
+                uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
+                if (y > 0) {
+                    const uint32_t tag = (a.seq << 12) | (uint32_t)y;          // row y-1 carries tag (y-1)+1
+                    const int slot = (y - 1) & (VDD_RING - 1);
+                    if (edge_l) if (lane_l) {                       // my pixel 0: column x0 - 1 lives in the left strip
+                        const unsigned long long* g = gleft + slot * VDD_GRAN;
+                        uint32_t vd = P2pk;
+                        if (!vdd_poll_n<NP>(g + NP * dl, g + 32, true, tag, p1, vd, budget)) { failed = true; budget = 0; }
+                        d1 = vd;
+                    }
+                    if (edge_r) if (lane_r) {                       // my last pixel: column x0 + PXS lives in the right strip
+                        const unsigned long long* g = gright + slot * VDD_GRAN;
+                        uint32_t vd = P2pk;
+                        if (!vdd_poll_n<NP>(g + NP * dl, g + 32, true, tag, p3, vd, budget)) { failed = true; budget = 0; }
+                        d3 = vd;
+                    }
+                }
+                // ---- 2. the two diagonal recurrences first: their edge values are what the neighbour strips wait for ----
                 uint32_t L1[NP], L2[NP], L3[NP];
                 uint32_t nd1 = chain_step<NP, LPP>(p1, d1, cv, L1, P1pk, P2pk, first_lane, last_lane);
-                uint32_t nd2 = chain_step<NP, LPP>(p2, d2, cv, L2, P1pk, P2pk, first_lane, last_lane);
                 uint32_t nd3 = chain_step<NP, LPP>(p3, d3, cv, L3, P1pk, P2pk, first_lane, last_lane);
                 if (!colok) {                                       // columns beyond the image: out-of-image state
 #pragma unroll
                     for (int i = 0; i < NP; i++) L1[i] = L3[i] = 0u;
                     nd1 = nd3 = P2pk;
                 }
-#pragma unroll
-                for (int i = 0; i < NP; i++) p2[i] = L2[i];
-                d2 = nd2;
-                if (colok) {
-                    uint32_t o[NP];
-#pragma unroll
-                    for (int i = 0; i < NP; i++) o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]);
-                    *reinterpret_cast<Vec*>(Sp + (size_t)y * rstride) = Packer<NP>::go(o);
-                }
-                // ---- 3. publish row y: LDS for the strip, granules for the neighbours ----
-                sL1[cur][px + 1][dl] = Packer<NP>::go(L1);
-                sL3[cur][px + 1][dl] = Packer<NP>::go(L3);
-                if (dl == 0) sDl[cur][px + 1] = make_uint2(nd1, nd3);
+                // ---- 3. publish row y as early as possible: granules for the neighbours, LDS for the strip ----
                 if (y + 1 < H) {
                     const uint32_t tag = (a.seq << 12) | (uint32_t)(y + 1);
                     const int slot = y & (VDD_RING - 1);
@@ -727,6 +720,20 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                         for (int i = 0; i < NP; i++) vdd_put(g + NP * dl + i, L3[i], tag);
                         if (dl == 0) vdd_put(g + 32, nd3, tag);
                     }
+                }
+                sL1[cur][px + 1][dl] = Packer<NP>::go(L1);
+                sL3[cur][px + 1][dl] = Packer<NP>::go(L3);
+                if (dl == 0) sDl[cur][px + 1] = make_uint2(nd1, nd3);
+                // ---- 4. the vertical recurrence and the sum ----
+                const uint32_t nd2 = chain_step<NP, LPP>(p2, d2, cv, L2, P1pk, P2pk, first_lane, last_lane);
+#pragma unroll
+                for (int i = 0; i < NP; i++) p2[i] = L2[i];
+                d2 = nd2;
+                if (colok) {
+                    uint32_t o[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; i++) o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]);
+                    *reinterpret_cast<Vec*>(Sp + (size_t)y * rstride) = Packer<NP>::go(o);
                 }
             }
         }
