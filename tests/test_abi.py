@@ -50,3 +50,19 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
                 assert "liboracle" not in src, f"{f} references the oracle library"
+
+
+def test_bench_algorithmic_bytes_match_the_survey():
+    """bench.py's per-launch shares must sum to SURVEY.md 8(d): 1 291 161 600 B (SGBM) and 190 771 200 B (guided)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    sg, gf = mod.alg_bytes_per_frame()
+    assert int(sum(sg.values())) == 1291161600 and gf["guided_sweep1+2"] == 190771200

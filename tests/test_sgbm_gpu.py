@@ -188,3 +188,50 @@ def test_lockstep_top_down_kernel(native, oracle, monkeypatch, W, H, n, dpl):
             want = oracle.sgbm_compute(*pairs[i])
             assert not mismatch_report(got[i], want, f"vdd frame {i} rep {rep}"), mismatch_report(got[i], want, f"vdd frame {i} rep {rep}")
     m.close()
+
+
+PARAM_SETS = [
+    dict(uniquenessRatio=0),
+    dict(uniquenessRatio=100),
+    dict(uniquenessRatio=35, disp12MaxDiff=3),
+    dict(speckleWindowSize=0),
+    dict(speckleWindowSize=400, speckleRange=1),
+    dict(preFilterCap=31, P1=200, P2=900),
+    dict(P1=8, P2=32),
+    dict(P1=1500, P2=9000, mode=1),
+    dict(disp12MaxDiff=10, uniquenessRatio=5, speckleWindowSize=30, speckleRange=4, mode=1),
+]
+
+
+@pytest.mark.parametrize("kw", PARAM_SETS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("vdd", ["1", "0"])
+def test_parameter_sweep(native, oracle, monkeypatch, kw, vdd):
+    """every StereoSGBM_create keyword the build accepts, away from depth.py's values, through both the
+    lock-step (k_vdd + k_hfused) and the per-direction (k_chain) code paths"""
+    monkeypatch.setenv("V3D_VDD", vdd)
+    monkeypatch.setenv("V3D_HFUSED", vdd)
+    W, H = 250, 64
+    L, R = textured_pair(W, H, seed=sum(kw.values()) + 3)
+    want = oracle.sgbm_compute(L, R, oracle.default_params(**kw))
+    m = native.StereoSGBM(max_width=W, max_height=H, **kw)
+    got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    assert m.sync_errors() == 0
+    m.close()
+    assert not mismatch_report(got, want, str(kw)), mismatch_report(got, want, str(kw))
+
+
+def test_noise_and_flat_inputs(native, oracle, matcher):
+    """no structure at all (pure noise: most pixels rejected) and piecewise-flat input (massive cost ties)"""
+    rng = np.random.default_rng(77)
+    W, H = 300, 70
+    L = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    R = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    got = matcher.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    assert not mismatch_report(got, oracle.sgbm_compute(L, R), "noise")
+    flat = np.repeat(np.repeat(rng.integers(0, 256, (H // 10, W // 20), dtype=np.uint8), 10, axis=0), 20, axis=1)
+    flatR = np.roll(flat, -6, axis=1)
+    got = matcher.compute(_dev(native, flat), _dev(native, flatR)).cpu().numpy()
+    assert not mismatch_report(got, oracle.sgbm_compute(flat, flatR), "flat")
+    sat = np.where(rng.random((H, W)) < 0.5, 0, 255).astype(np.uint8)          # saturated gradients everywhere
+    got = matcher.compute(_dev(native, sat), _dev(native, np.roll(sat, -11, axis=1))).cpu().numpy()
+    assert not mismatch_report(got, oracle.sgbm_compute(sat, np.roll(sat, -11, axis=1)), "binary")
