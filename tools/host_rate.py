@@ -15,7 +15,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 be = ex.backend
 def fused():
     d = be.sbs_to_disparity(frames, True)          # H2D 8 x 6.2 MB, kernels, result stays on device
-    return d.cpu().numpy()                         # D2H 8 x 8.3 MB
+    return be.depth_to_host(d)                     # D2H 8 x 8.3 MB through pinned memory
 for _ in range(2): fused()
 t0 = time.perf_counter(); n = 5
 for _ in range(n): out = fused()

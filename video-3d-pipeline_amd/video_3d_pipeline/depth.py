@@ -82,22 +82,44 @@ class HipStereoBackend:
         self._check_lockstep(matcher)
         return [out[i] for i in range(n)]
 
+    def _staging(self, key, shape, dtype, pinned):
+        """reusable buffers: pinned host staging + device tensors (no allocation on the steady-state path)"""
+        torch = self.torch
+        bufs = self.__dict__.setdefault("_bufs", {})
+        t = bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, pin_memory=True) if pinned else torch.empty(shape, dtype=dtype, device=self.device)
+            bufs[key] = t
+        return t
+
     def sbs_to_disparity(self, frames: List[np.ndarray], unsqueeze: bool):
-        """fused path: SBS BGR frames -> device float32 disparity [n,H,W] (no BGR halves materialised)"""
+        """fused path: SBS BGR frames -> device float32 disparity [n,H,W] (no BGR halves materialised).
+        Frames are gathered into one pinned buffer and cross PCIe in a single asynchronous copy."""
         torch, nat = self.torch, self.native
         n = len(frames)
         H, W = frames[0].shape[:2]
         ow = W if unsqueeze else W // 2
-        lg = torch.empty((n, H, ow), dtype=torch.uint8, device=self.device)
-        rg = torch.empty_like(lg)
+        host = self._staging("sbs_host", (n, H, W, 3), torch.uint8, True)
+        hview = host.numpy()
         for i, f in enumerate(frames):
-            l, r = nat.sbs_to_gray(nat.to_device(f, self.device), unsqueeze)
-            lg[i], rg[i] = l, r
+            hview[i] = f
+        dev = self._staging("sbs_dev", (n, H, W, 3), torch.uint8, False)
+        dev.copy_(host, non_blocking=True)
+        lg = self._staging("lg", (n, H, ow), torch.uint8, False)
+        rg = self._staging("rg", (n, H, ow), torch.uint8, False)
+        nat.sbs_to_gray_batch(dev, unsqueeze, (lg, rg))
         matcher = self._get_matcher(ow, H, n)
-        disp = matcher.compute(lg, rg)
-        depth = nat.disp_to_depth(disp)
+        disp = matcher.compute(lg, rg, self._staging("disp", (n, H, ow), torch.int16, False))
+        depth = nat.disp_to_depth(disp, self._staging("depth", (n, H, ow), torch.float32, False))
         self._check_lockstep(matcher)
         return depth
+
+    def depth_to_host(self, depth) -> np.ndarray:
+        """device float32 [n,H,W] -> NumPy through a pinned buffer"""
+        host = self._staging("depth_host", tuple(depth.shape), self.torch.float32, True)
+        host.copy_(depth, non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+        return host.numpy().copy()
 
     def normalise_u16(self, depth) -> np.ndarray:
         nat = self.native
