@@ -258,9 +258,10 @@ def main():
         achieved = dk["alg_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9
         traffic = None                     # PMC counters cannot be read in-process: taken from the committed rocprofv3 --pmc passes
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            tfile = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = tfile["kernels"]
             if dom in tj:
-                traffic = int(tj[dom]["traffic_bytes"] * B / tj.get("_frames_per_launch", 8))
+                traffic = int(tj[dom]["traffic_bytes"] * B / tfile.get("_frames_per_launch", 30))
         except (OSError, KeyError, ValueError):
             pass
         sgbm_ms = sum(v["avg_ms"] for k, v in kernels.items() if not k.startswith("guided"))

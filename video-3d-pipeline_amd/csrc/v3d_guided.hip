@@ -14,6 +14,16 @@
 // 1e-3 *relative* parity bar cannot be met there with f32 cancellation in cov/var and in box(b).
 #include "v3d_common.h"
 
+// 1/x to full double precision: v_rcp_f64 seed (~26 bits) + two Newton steps (5 instructions instead of the
+// ~30 of an IEEE division; the last-ulp difference is far inside the 1e-3 parity bar)
+__device__ __forceinline__ double gf_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 #define GF_TX 64
 #define GF_RUN 8      // outputs per thread along x in the horizontal pass
 #define GF_RMAX 16
@@ -224,12 +234,12 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                             if (SWEEP == 1) { sg += sVi[buf][0][tid + k]; sgg += sVi[buf][1][tid + k]; }
                         }
                         const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
-                        const double inv = 1.0 / (double)(cx * cy);   // one f64 division instead of four (1 ulp, far inside 1e-3)
+                        const double inv = gf_rcp((double)(cx * cy));
                         if (SWEEP == 1) {
                             const double mI = (double)sg * (inv * (1.0 / 255.0)), mp = s0 * inv;
                             const double mII = (double)sgg * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
                             const double var = mII - mI * mI, cov = mIp - mI * mp;
-                            const double a = cov / (var + eps);
+                            const double a = cov * gf_rcp(var + eps);
                             A[(size_t)y * W + gx] = a;
                             B[(size_t)y * W + gx] = mp - a * mI;
                         } else {
