@@ -76,4 +76,47 @@ __device__ __forceinline__ uint32_t dpp_xchg(uint32_t src)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xF, 0xF, true);
 }
+// streaming accesses: once-read / once-written volume data bypasses cache retention (V3D_NT=0 at build time to disable)
+#ifndef V3D_NT
+#define V3D_NT 1
+#endif
+typedef uint32_t v3d_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t v3d_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 ld_stream(const uint4* p)
+{
+#if V3D_NT
+    const v3d_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2* p)
+{
+#if V3D_NT
+    const v3d_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x2*>(p));
+    return make_uint2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v)
+{
+#if V3D_NT
+    v3d_u32x4 t = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(t, reinterpret_cast<v3d_u32x4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint2* p, uint2 v)
+{
+#if V3D_NT
+    v3d_u32x2 t = { v.x, v.y };
+    __builtin_nontemporal_store(t, reinterpret_cast<v3d_u32x2*>(p));
+#else
+    *p = v;
+#endif
+}
+
 #endif

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, co
                 o.x = vs01 + P2pk; o.y = vs23 + P2pk;
                 const int y = ys + k - 4;
                 const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq;
-                *reinterpret_cast<uint2*>(Cf + off) = o;
+                if (FUSE_V) *reinterpret_cast<uint2*>(Cf + off) = o; else st_stream(reinterpret_cast<uint2*>(Cf + off), o);
                 if (FUSE_V) {
                     const uint32_t cv[2] = { o.x, o.y };
                     uint32_t L[2];
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
             // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
             Vec cb[K];
 #pragma unroll
-            for (int jj = 0; jj < K; jj++) cb[jj] = *reinterpret_cast<const Vec*>(Crow + (size_t)(xb + jj) * V3D_D);
+            for (int jj = 0; jj < K; jj++) cb[jj] = ld_stream(reinterpret_cast<const Vec*>(Crow + (size_t)(xb + jj) * V3D_D));
 #pragma unroll
             for (int jj = 0; jj < K; jj++) {
                 uint32_t cv[NP], L[NP];
@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 #pragma unroll
         for (int j = 0; j < K; j++) {
             const size_t o = (size_t)min(x0 + j, W1 - 1) * V3D_D;
-            cvv[j] = *reinterpret_cast<const Vec*>(Crow + o);
-            svv[j] = *reinterpret_cast<const Vec*>(Srow + o);
+            cvv[j] = ld_stream(reinterpret_cast<const Vec*>(Crow + o));
+            svv[j] = ld_stream(reinterpret_cast<const Vec*>(Srow + o));
         }
         uint32_t p[NP], delta = P2pk;
 #pragma unroll
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
 
     Vec cq[PF];
 #pragma unroll
-    for (int j = 0; j < PF; j++) cq[j] = *reinterpret_cast<const Vec*>(Cp + (size_t)min(j, H - 1) * rstride);
+    for (int j = 0; j < PF; j++) cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + (size_t)min(j, H - 1) * rstride));
     __syncthreads();
 
     for (int y0 = 0; y0 < H; y0 += PF) {
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 //         strips' granules, polled AFTER the barrier so the other 14 waves compute meanwhile ----
                 uint32_t cv[NP], p1[NP], p3[NP];
                 vec_unpack<NP>(cq[j], cv);
-                cq[j] = *reinterpret_cast<const Vec*>(Cp + (size_t)min(y + PF, H - 1) * rstride);
+                cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + (size_t)min(y + PF, H - 1) * rstride));
                 vec_unpack<NP>(sL1[prev][px][dl], p1);             // column x-1 (slot px holds pixel px-1)
                 vec_unpack<NP>(sL3[prev][px + 2][dl], p3);         // column x+1
                 uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                     uint32_t o[NP];
 #pragma unroll
                     for (int i = 0; i < NP; i++) o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]);
-                    *reinterpret_cast<Vec*>(Sp + (size_t)y * rstride) = Packer<NP>::go(o);
+                    st_stream(reinterpret_cast<Vec*>(Sp + (size_t)y * rstride), Packer<NP>::go(o));
                 }
             }
         }
