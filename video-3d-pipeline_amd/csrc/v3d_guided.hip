@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                     v0 += pn - po; v1 += (double)gn * pn - (double)go * po;
                 } else {
                     double n0 = 0.0, n1 = 0.0;
-                    if (in) { n0 = A[(size_t)e * W + gx]; n1 = B[(size_t)e * W + gx]; }
+                    if (in) { n0 = __builtin_nontemporal_load(A + (size_t)e * W + gx); n1 = __builtin_nontemporal_load(B + (size_t)e * W + gx); }
                     const double o0 = r0[j], o1 = r1[j];
                     r0[j] = n0; r1[j] = n1;
                     v0 += n0 - o0; v1 += n1 - o1;
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                             const double mII = (double)sgg * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
                             const double var = mII - mI * mI, cov = mIp - mI * mp;
                             const double a = cov * gf_rcp(var + eps);
-                            A[(size_t)y * W + gx] = a;
-                            B[(size_t)y * W + gx] = mp - a * mI;
+                            __builtin_nontemporal_store(a, A + (size_t)y * W + gx);
+                            __builtin_nontemporal_store(mp - a * mI, B + (size_t)y * W + gx);
                         } else {
                             const double I = (double)guide[(size_t)y * W + gx] * (1.0 / 255.0);
-                            out[(size_t)y * W + gx] = (float)((s0 * inv) * I + (s1 * inv));
+                            __builtin_nontemporal_store((float)((s0 * inv) * I + (s1 * inv)), out + (size_t)y * W + gx);
                         }
                     }
                 }

@@ -806,10 +806,23 @@ __device__ __forceinline__ int ccl_find(const int* L, int i)
     while (p != i) { i = p; p = ccl_ld(L, i); }
     return i;
 }
+// find with path halving: every visited node is re-pointed at its grandparent.  Safe next to concurrent
+// atomicMin hooks: a node is only ever re-pointed at one of its own ancestors, never at a slot seen as a root.
+__device__ __forceinline__ int ccl_find_halve(int* L, int i)
+{
+    for (;;) {
+        const int p = ccl_ld(L, i);
+        if (p == i) return i;
+        const int gp = ccl_ld(L, p);
+        if (gp == p) return p;
+        __hip_atomic_store(L + i, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i = gp;
+    }
+}
 __device__ __forceinline__ void ccl_union(int* L, int a, int b)
 {
     for (;;) {
-        a = ccl_find(L, a); b = ccl_find(L, b);
+        a = ccl_find_halve(L, a); b = ccl_find_halve(L, b);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang the larger root under the smaller
         const int old = atomicMin(L + a, b);
