@@ -44,7 +44,7 @@ def alg_bytes_per_frame():
         "cost": V,                                # C write
         "chain_v2": 2 * V / 3, "chain_d1": 2 * V / 3, "chain_d3": 2 * V / 3,   # K_v: C read + S write, 3 launches
         "chain_h0": V, "chain_h4_wta": V + 2 * P,                              # K_h: C read + S read, + disp16 out
-        "chain_v2r": 0, "chain_d1r": 0, "chain_d3r": 0, "lrcheck": 0, "median": 0, "speckles": 0,
+        "chain_v2r": 0, "chain_d1r": 0, "chain_d3r": 0, "lrcheck": 0, "median": 0, "speckles": 0,     # (8-path extras: no share)
     }
     P4 = P * SCALE * SCALE
     gf = {"guided_sweep1+2": 2 * P4 + 4 * P + 4 * P4 * 2 * 2 + 4 * P4}          # 190 771 200 B (survey figure)
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="auto",
                     help="how rank 0 hands out the 4K guide rounds: broadcast the whole round (north_star), scatter each rank's "
                          "frames (world x fewer bytes), or auto = broadcast if it hides behind one compute step, else scatter")
+    ap.add_argument("--sgbm-mode", choices=["sgbm", "hh"], default="sgbm",
+                    help="sgbm = OpenCV MODE_SGBM, 5 paths (what depth.py:315-325 gets by default); hh = MODE_HH, 8 paths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
@@ -140,7 +142,7 @@ def main():
     disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
     depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     out4k = torch.empty((B, Hh, Wh), dtype=torch.float32, device=dev)
-    matcher = N.StereoSGBM(W, H, B, device=local)
+    matcher = N.StereoSGBM(W, H, B, device=local, mode=1 if args.sgbm_mode == "hh" else 0)
 
     def exchange(slot):
         """enqueue the guide exchange for the NEXT step on the side stream"""
@@ -275,7 +277,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 (SGM) + f32 (guided filter)", "data": "synthetic",
             "config": {"workload": "configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth",
-                       "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_SGBM (5 paths)",
+                       "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_HH (8 paths)" if args.sgbm_mode == "hh" else "MODE_SGBM (5 paths)",
                        "guided_radius": 8, "guided_eps": 1e-3, "parallelism": f"frames round-robin over {world} GPU(s)",
                        "guide_exchange": (mode["v"] if world > 1 else "local"), "guide_exchange_probe": exch_info},
             "p50_ms_per_frame": statistics.median(step_ms) / B,

@@ -611,7 +611,9 @@ __device__ __forceinline__ void vdd_put(unsigned long long* g, uint32_t v, uint3
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int DPL>
+// YREV: the same pass bottom-up (MODE_HH's second half: predecessors (x-1,y+1), (x,y+1), (x+1,y+1)), accumulating
+// into the S the top-down pass left behind (S += L1 + L2 + L3, saturating).
+template <int DPL, bool YREV>
 __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD = two workgroups per CU: the second hides the hand-off latency
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, PXS = 16 * PPW;   // PXS = columns per strip (64 / 128)
@@ -660,8 +662,10 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     for (int i = 0; i < NP; i++) p2[i] = 0u;
 
     Vec cq[PF];
+    auto rowof = [&](int y) -> size_t { const int yc = min(y, H - 1); return (size_t)(YREV ? H - 1 - yc : yc) * rstride; };
+    Vec sq[PF];
 #pragma unroll
-    for (int j = 0; j < PF; j++) cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + (size_t)min(j, H - 1) * rstride));
+    for (int j = 0; j < PF; j++) { cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(j))); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
     __syncthreads();
 
     for (int y0 = 0; y0 < H; y0 += PF) {
@@ -674,8 +678,11 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 // ---- 1. predecessors: strip neighbours from LDS; the two edge pixels take theirs from the neighbour
                 //         strips' granules, polled AFTER the barrier so the other 14 waves compute meanwhile ----
                 uint32_t cv[NP], p1[NP], p3[NP];
+                uint32_t sold[NP];
                 vec_unpack<NP>(cq[j], cv);
-                cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + (size_t)min(y + PF, H - 1) * rstride));
+                if (YREV) vec_unpack<NP>(sq[j], sold);
+                cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y + PF)));
+                if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(y + PF)));
                 vec_unpack<NP>(sL1[prev][px][dl], p1);             // column x-1 (slot px holds pixel px-1)
                 vec_unpack<NP>(sL3[prev][px + 2][dl], p3);         // column x+1
                 uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
@@ -732,8 +739,8 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 if (colok) {
                     uint32_t o[NP];
 #pragma unroll
-                    for (int i = 0; i < NP; i++) o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]);
-                    st_stream(reinterpret_cast<Vec*>(Sp + (size_t)y * rstride), Packer<NP>::go(o));
+                    for (int i = 0; i < NP; i++) { o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]); if (YREV) o[i] = pk_add_sat(o[i], sold[i]); }
+                    st_stream(reinterpret_cast<Vec*>(Sp + rowof(y)), Packer<NP>::go(o));
                 }
             }
         }
@@ -1039,8 +1046,8 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         h->vdd_mode = (e4 && atoi(e4) == 0) ? 0 : 1;      // default on; V3D_VDD=0 falls back to three k_chain launches
         // all strips of a launch must be resident together: bound frames per launch by the occupancy query, with margin
         int b4 = 0, b8 = 0, ncu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_vdd<4>, 1024, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, k_vdd<8>, 1024, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_vdd<4, true>, 1024, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, k_vdd<8, true>, 1024, 0);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         if (b4 > 2) b4 = 2;
         if (b8 > 2) b8 = 2;
@@ -1090,6 +1097,26 @@ static int check_geometry(const v3d_sgbm* h, int n, int W, int H, int pitch)
     return V3D_OK;
 }
 
+// one lock-step pass over the three top-down (or, rev, bottom-up) paths; frames per launch bounded by co-residency.
+// mapping: 4 disparities per lane (64-column strips) while the whole batch fits one co-resident launch, else
+// 8 per lane (128-column strips: ~30 % fewer instructions per element, twice the frames per launch)
+static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t st)
+{
+    const int dpl = h->vdd_dpl ? h->vdd_dpl : (n <= h->vdd_mf4 ? 4 : 8);
+    const int mf = dpl == 8 ? h->vdd_mf8 : h->vdd_mf4;
+    for (int f0 = 0; f0 < n; f0 += mf) {
+        VddArgs v;
+        const int nf = n - f0 < mf ? n - f0 : mf;
+        v.C = h->C + (size_t)f0 * H * W1 * V3D_D; v.S = h->S + (size_t)f0 * H * W1 * V3D_D;
+        v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
+        v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
+        v.gran = h->gran; v.err = h->vdd_err;
+        const dim3 grid(v.nstrips * nf), block(1024);
+        if (dpl == 8) { if (rev) hipLaunchKernelGGL((k_vdd<8, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<8, false>), grid, block, 0, st, v); }
+        else { if (rev) hipLaunchKernelGGL((k_vdd<4, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<4, false>), grid, block, 0, st, v); }
+    }
+}
+
 // stages: 1 = cost volume, 2 = aggregation + WTA + LR check (raw), 3 = median + speckles (final)
 static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int n, int W, int H, int pitch,
                     size_t frame_stride, int16_t* out, int last_stage, hipStream_t st)
@@ -1116,22 +1143,12 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     a.dispw = h->dispw; a.d2key = h->d2key;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
-    if (h->vdd_mode && !vf && H < 4095) {
+    const bool use_vdd = h->vdd_mode && !vf && H < 4095;
+    if (use_vdd) {
         // r1 + r2 + r3 in one lock-step pass (k_vdd); frames per launch bounded by co-residency
         // mapping: 4 disparities per lane (64-column strips) while the whole batch fits one co-resident launch, else
         // 8 per lane (128-column strips: ~30 % fewer instructions per element, twice the frames per launch)
-        const int dpl = h->vdd_dpl ? h->vdd_dpl : (n <= h->vdd_mf4 ? 4 : 8);
-        const int mf = dpl == 8 ? h->vdd_mf8 : h->vdd_mf4;
-        for (int f0 = 0; f0 < n; f0 += mf) {
-            VddArgs v;
-            const int nf = n - f0 < mf ? n - f0 : mf;
-            v.C = h->C + (size_t)f0 * H * W1 * V3D_D; v.S = h->S + (size_t)f0 * H * W1 * V3D_D;
-            v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
-            v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
-            v.gran = h->gran; v.err = h->vdd_err;
-            if (dpl == 8) hipLaunchKernelGGL(k_vdd<8>, dim3(v.nstrips * nf), dim3(1024), 0, st, v);
-            else hipLaunchKernelGGL(k_vdd<4>, dim3(v.nstrips * nf), dim3(1024), 0, st, v);
-        }
+        launch_vdd(h, n, W1, H, false, st);
         prof_mark(h, ST_D1, st);
         prof_mark(h, ST_D3, st);
     } else {
@@ -1145,11 +1162,16 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     if (!h->hfused) launch_chain<true, 1, false, 1>(h, a, st);          // r0: (x-1, y)
     prof_mark(h, ST_V2R, st);
     if (h->prm.mode == V3D_MODE_HH) {
-        launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
-        prof_mark(h, ST_D1R, st);
-        launch_chain<false, -1, true, 1>(h, a, st);     // (x+1, y+1)
-        prof_mark(h, ST_D3R, st);
-        launch_chain<false, 1, true, 1>(h, a, st);      // (x-1, y+1)
+        if (use_vdd) {
+            launch_vdd(h, n, W1, H, true, st);              // (x-1,y+1), (x,y+1), (x+1,y+1) in one bottom-up lock-step pass
+            prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st);
+        } else {
+            launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
+            prof_mark(h, ST_D1R, st);
+            launch_chain<false, -1, true, 1>(h, a, st);     // (x+1, y+1)
+            prof_mark(h, ST_D3R, st);
+            launch_chain<false, 1, true, 1>(h, a, st);      // (x-1, y+1)
+        }
     } else { prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st); }
     prof_mark(h, ST_H4_WTA, st);
     if (h->hfused) {                                    // r0 + r4 + WTA tail in one launch
