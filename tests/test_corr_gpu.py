@@ -47,3 +47,18 @@ def test_rejects_bad_channels(native):
     a = torch.zeros((4, 16, 48), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(native.NativeError):
         native.corr_lookup(a, a, torch.zeros((2, 4, 16), device="cuda"), 1, 0)
+
+
+def test_fused_gather_gemm_is_bit_identical(native, monkeypatch):
+    """V3D_CORR_GATHER=1 builds the B operand on the fly (no materialised warp): same bits, measured slower"""
+    h, w, G = 10, 40, 2
+    g = torch.Generator(device="cpu").manual_seed(3)
+    fl = torch.randn((h, w, 64 * G), generator=g).to("cuda", torch.bfloat16)
+    fr = torch.randn((h, w, 64 * G), generator=g).to("cuda", torch.bfloat16)
+    flow = (torch.rand((2, h, w), generator=g) * 6 - 3).cuda()
+    for pat in (0, 1):
+        a = native.corr_lookup(fl, fr, flow, G, pat)
+        monkeypatch.setenv("V3D_CORR_GATHER", "1")
+        b = native.corr_lookup(fl, fr, flow, G, pat)
+        monkeypatch.delenv("V3D_CORR_GATHER")
+        assert torch.equal(a, b)

@@ -11,6 +11,7 @@
 // are picked out of the accumulators.  Arithmetic intensity is ~4 flop/B: the kernel is HBM/L2
 // bound, MFMA only removes the VALU bottleneck.
 #include "v3d_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -109,6 +110,98 @@ __global__ __launch_bounds__(256) void k_corr(const unsigned short* __restrict__
     }
 }
 
+// gather-GEMM: one wave = 16 consecutive pixels of one row, all groups; 4 waves per block.  The B operand
+// (warped right features) is never materialised: every lane owns one warped position of the N tile, turns
+// its flow vector into 4 bilinear taps once per tile row, and for every (group, k-step) gathers its 8
+// channels from the 4 taps (4 x 16-B loads, L2-resident), blends them in f32 and rounds to bf16 -- exactly
+// the value k_corr_warp would have stored.
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k_corr_gather(const unsigned short* __restrict__ fl, const unsigned short* __restrict__ fr,
+                                                     const float* __restrict__ flow, int C, int h, int w, int G,
+                                                     float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int xtiles = (w + 15) >> 4;
+    const int gw = blockIdx.x * 4 + wib;
+    if (gw >= xtiles * h) return;
+    const int y = gw / xtiles, x0 = (gw - y * xtiles) << 4;
+    const int r16 = lane & 15, q = lane >> 4;                 // MFMA operand row/col and k-quarter
+    const size_t hw = (size_t)h * w;
+    const float scale = 1.0f / 64.0f;
+    constexpr int NROW = PATTERN == 0 ? 1 : 3;
+    const int xa = min(x0 + r16, w - 1);                       // A operand: pixel x0 + r16
+
+#pragma unroll
+    for (int ry = 0; ry < NROW; ry++) {
+        const int dy = PATTERN == 0 ? 0 : ry - 1;
+        const int yy = min(max(y + dy, 0), h - 1);
+        // bilinear taps of my two warped positions (one per N tile)
+        const unsigned short* tap[2][4]; float wt[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int xb = min(max(x0 - 4 + n * 16 + r16, 0), w - 1);
+            const size_t pix = (size_t)yy * w + xb;
+            const float sx = xb + flow[pix], sy = yy + flow[hw + pix];
+            const float x0f = floorf(sx), y0f = floorf(sy);
+            const float wx = sx - x0f, wy = sy - y0f;
+            const int ix = (int)x0f, iy = (int)y0f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int xx = ix + (t & 1), yv = iy + (t >> 1);
+                const bool in = xx >= 0 && xx < w && yv >= 0 && yv < h;
+                wt[n][t] = in ? ((t & 1) ? wx : 1.f - wx) * ((t >> 1) ? wy : 1.f - wy) : 0.f;     // zeros outside
+                tap[n][t] = fr + ((size_t)min(max(yv, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C;
+            }
+        }
+        for (int g = 0; g < G; g++) {
+            bf16x8 a[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                a[ks] = *reinterpret_cast<const bf16x8*>(fl + ((size_t)y * w + xa) * C + g * 64 + ks * 32 + q * 8);
+            f32x4 acc[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                acc[n] = (f32x4){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int co = g * 64 + ks * 32 + q * 8;
+                    float bl[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bl[k] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {              // same tap order as the oracle: (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+                        const uint4 v = *reinterpret_cast<const uint4*>(tap[n][t] + co);
+                        const unsigned u[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            bl[2 * k] += bf2f((unsigned short)(u[k] & 0xFFFFu)) * wt[n][t];
+                            bl[2 * k + 1] += bf2f((unsigned short)(u[k] >> 16)) * wt[n][t];
+                        }
+                    }
+                    bf16x8 bq;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bq[k] = (__bf16)bl[k];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bq, acc[n], 0, 0, 0);
+                }
+            }
+            // accumulator element (reg r) of this lane: pixel i = 4q + r, position column j = r16 of tile n
+            //   -> window offset k = j - i + 16 n  (dx = k - 4), wanted when 0 <= k <= 8 (1x9) or 3 <= k <= 5 (3x3)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = 4 * q + r;
+                    const int k = r16 - i + 16 * n;
+                    const int x = x0 + i;
+                    bool want; int plane;
+                    if (PATTERN == 0) { want = (k >= 0 && k <= 8); plane = g * 9 + k; }
+                    else { want = (k >= 3 && k <= 5); plane = g * 9 + ry * 3 + (k - 3); }
+                    if (want && x < w) out[(size_t)plane * hw + (size_t)y * w + x] = acc[n][r] * scale;
+                }
+        }
+    }
+}
+
 extern "C" size_t v3d_corr_ws_bytes(int C, int h, int w)
 {
     if (C < 1 || h < 1 || w < 1) return 0;
@@ -123,6 +216,15 @@ extern "C" int v3d_corr_lookup(const uint16_t* fl, const uint16_t* fr, const flo
     if (h < 1 || w < 1) { v3d_set_error("bad geometry"); return V3D_ERR_ARG; }
     if (pattern != 0 && pattern != 1) { v3d_set_error("pattern must be 0 (1x9) or 1 (3x3)"); return V3D_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    const int nwaves = ((w + 15) / 16) * h;
+    // measured (270x480x256, MI355X): warp + GEMM 67 us (1x9) / 91 us (3x3); fused gather-GEMM 76 / 198 us -- the per-use
+    // bilinear blend makes the fused form VALU-bound, so the materialised warp stays the default
+    if (getenv("V3D_CORR_GATHER")) {
+        if (pattern == 0) hipLaunchKernelGGL(k_corr_gather<0>, dim3(v3d_cdiv(nwaves, 4)), dim3(256), 0, st, fl, fr, flow, C, h, w, G, out);
+        else hipLaunchKernelGGL(k_corr_gather<1>, dim3(v3d_cdiv(nwaves, 4)), dim3(256), 0, st, fl, fr, flow, C, h, w, G, out);
+        V3D_LAUNCH_CHECK();
+        return V3D_OK;
+    }
     unsigned short* frw = reinterpret_cast<unsigned short*>(ws);
     const size_t nthreads = (size_t)h * w * (C / 8);
     hipLaunchKernelGGL(k_corr_warp, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, fr, flow, C, h, w, frw);
