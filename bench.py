@@ -82,6 +82,39 @@ def cpu_baseline(sbs, guide):
     return out
 
 
+def bench_corr(args, N):
+    """BASELINE configs[3]: CREStereo-style correlation lookup, bf16 in / f32 accumulate on MFMA, 1080p/4 features"""
+    h, w, C, G = 270, 480, 256, 4
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    fl = torch.randn((h, w, C), device=dev).to(torch.bfloat16)
+    fr = torch.randn((h, w, C), device=dev).to(torch.bfloat16)
+    flow = torch.rand((2, h, w), device=dev) * 4 - 2
+    for _ in range(args.warmup):
+        N.corr_lookup(fl, fr, flow, G, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        N.corr_lookup(fl, fr, flow, G, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    alg = 2 * h * w * C * 2 + 2 * h * w * 4 + G * 9 * h * w * 4           # fl + fr bf16, flow, out f32 (SURVEY 8d: ~142 MB form A)
+    flops = 2.0 * h * w * C * 9
+    print(json.dumps({"metric": "corr_lookups_per_s", "value": args.steps / el, "unit": "lookups/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "bf16 in / f32 accumulate (MFMA 16x16x32)", "data": "synthetic",
+                      "config": {"workload": "configs[3]: correlation lookup 270x480x256, 4 groups x 9 offsets (1x9)"},
+                      "roofline": {"bound": "hbm", "kernel": "k_corr_warp + k_corr<0>", "achieved": alg / (ms * 1e-3) / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "useful_gflops": flops / (ms * 1e-3) / 1e9,
+                                   "note": "AI ~ 4 flop/B: HBM/L2 bound; MFMA only removes the VALU bottleneck"},
+                      "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +125,9 @@ def main():
     ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="auto",
                     help="how rank 0 hands out the 4K guide rounds: broadcast the whole round (north_star), scatter each rank's "
                          "frames (world x fewer bytes), or auto = broadcast if it hides behind one compute step, else scatter")
+    ap.add_argument("--workload", choices=["full", "sgbm", "corr"], default="full",
+                    help="full = BASELINE configs[2] (default, the headline metric); sgbm = configs[1] (disparity only); "
+                         "corr = configs[3] (bf16 MFMA correlation lookup, 270x480x256 features)")
     ap.add_argument("--sgbm-mode", choices=["sgbm", "hh"], default="sgbm",
                     help="sgbm = OpenCV MODE_SGBM, 5 paths (what depth.py:315-325 gets by default); hh = MODE_HH, 8 paths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,6 +135,8 @@ def main():
     args = ap.parse_args()
 
     from video_3d_pipeline import _native as N, sharding, synthetic as syn
+    if args.workload == "corr":
+        return bench_corr(args, N)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +209,8 @@ def main():
         N.sbs_to_gray_batch(sbs, True, (lg, rg))
         matcher.compute(lg, rg, disp)
         N.disp_to_depth(disp, depth)
+        if args.workload == "sgbm":
+            return
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -253,7 +293,7 @@ def main():
         for name, total in stage_ms.items():
             if calls and total > 0:
                 kernels[name] = {"avg_ms": total / calls, "alg_bytes": sg.get(name, 0) * B}
-        gfa = sum(a.elapsed_time(b) for a, b in gf_ev) / max(len(gf_ev), 1)
+        gfa = sum(a.elapsed_time(b) for a, b in gf_ev) / max(len(gf_ev), 1) if gf_ev else 1e-9
         kernels["guided_sweep1+2"] = {"avg_ms": gfa, "alg_bytes": gf["guided_sweep1+2"] * B}    # launch pair over the batch
         dom = max((k for k in kernels if not k.startswith("guided")), key=lambda k: kernels[k]["avg_ms"])
         dk = kernels[dom]
@@ -269,14 +309,15 @@ def main():
         sgbm_ms = sum(v["avg_ms"] for k, v in kernels.items() if not k.startswith("guided"))
         sgbm_alg = sum(sg.values()) * B
         res = {
-            "metric": "1080p_sbs_to_4k_depth_frames_per_s",
+            "metric": "1080p_sbs_to_4k_depth_frames_per_s" if args.workload == "full" else "1080p_sbs_to_disparity_frames_per_s",
             "value": world * B * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 (SGM) + f32 (guided filter)", "data": "synthetic",
-            "config": {"workload": "configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth",
+            "config": {"workload": ("configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth" if args.workload == "full"
+                                    else "configs[1]: 1920x1080 SBS -> disparity (SBS split + SGBM + depth), no upscale"),
                        "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_HH (8 paths)" if args.sgbm_mode == "hh" else "MODE_SGBM (5 paths)",
                        "guided_radius": 8, "guided_eps": 1e-3, "parallelism": f"frames round-robin over {world} GPU(s)",
                        "guide_exchange": (mode["v"] if world > 1 else "local"), "guide_exchange_probe": exch_info},

@@ -230,3 +230,22 @@ def test_aligner_stub_is_explicit():
     from video_3d_pipeline.align import VideoAligner
     with pytest.raises(RuntimeError, match="skip-alignment"):
         VideoAligner("a", "b").find_alignment(300)
+
+
+def test_config0_geometry_plumbing(tmp_path):
+    """BASELINE.json configs[0]: a 960x540 synthetic SBS clip through the depth plumbing on CPU (stand-in backend;
+    the reference's own CPU-runnable case -- a parity/plumbing case, not a bench line).  8 frames keep it quick."""
+    from video_3d_pipeline import synthetic as syn
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.utils import read_png16
+    frames = np.stack([syn.sbs_frame(960, 540, i) for i in range(2)] * 4)
+    clip = tmp_path / "clip960.npy"
+    np.save(clip, frames)
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), batch_size=4,
+                                    stereo_only=True, backend=OracleStereoBackend())
+    out = ex.process_video_sbs(str(clip))
+    files = sorted(os.listdir(out))
+    assert len(files) == 8 and files[0] == "depth_000000.png"
+    a = read_png16(out / "depth_000000.png")
+    assert a.shape == (540, 960) and a.max() == 65535 and a.min() == 0           # per-frame min-max normalisation
+    assert np.array_equal(a, read_png16(out / "depth_000002.png"))                # identical input frame -> identical PNG
