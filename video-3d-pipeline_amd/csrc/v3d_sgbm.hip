@@ -79,10 +79,11 @@ __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t
 
 __device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
 {
-    // min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v)) on two disparities at once
-    uint32_t a = pk_max(pk_sub(U, V1), pk_sub(V0, U));
-    uint32_t b = pk_max(pk_sub(V, U1), pk_sub(U0, V));
-    return pk_max(pk_min(a, b), 0u);
+    // min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v)) on two disparities at once; all operands are 0..255, so
+    // unsigned saturating subtracts give the max(0, .) for free: 7 packed ops
+    const uint32_t a = pk_max(pk_subu_sat(U, V1), pk_subu_sat(V0, U));
+    const uint32_t b = pk_max(pk_subu_sat(V, U1), pk_subu_sat(U0, V));
+    return pk_min(a, b);
 }
 __device__ __forceinline__ uint32_t byte2(uint32_t a, int sa, uint32_t b, int sb)
 {
@@ -795,6 +796,53 @@ __global__ __launch_bounds__(256) void k_median3x3(const int16_t* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
+// a-7 + a-8 fused: L-R check and 3x3 median in one launch.  A block L-R-checks a 64 x 4 tile plus a
+// one-pixel ring into LDS (each pixel checked once, 1.6x halo work instead of 9x), then takes the medians
+// from LDS: saves a launch and the write + read of the intermediate image.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lr_checked(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
+                                          size_t rowo, int x, int W, int d12)
+{
+    if (x < V3D_D) return V3D_INVALID16;
+    int d1 = dispw[rowo + x];
+    if (d1 == V3D_INVALID16) return d1;
+    const int da = d1 >> 4, db = (d1 + 15) >> 4;
+    const int xa = x - da, xb = x - db;
+    bool bad = true;
+    if (xa >= 0 && xa < W) { const uint32_t k = d2key[rowo + xa]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - da) > d12); } else bad = false;
+    if (xb >= 0 && xb < W) { const uint32_t k = d2key[rowo + xb]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - db) > d12); } else bad = false;
+    return bad ? V3D_INVALID16 : d1;
+}
+
+#define LRM_TX 64
+#define LRM_TY 4
+__global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
+                                                        int W, int H, int d12, int16_t* __restrict__ out)
+{
+    __shared__ short sT[LRM_TY + 2][LRM_TX + 2];
+    const int t = threadIdx.x, f = blockIdx.z;
+    const int x0 = blockIdx.x * LRM_TX, y0 = blockIdx.y * LRM_TY;
+    const size_t fo = (size_t)f * H * W;
+    for (int i = t; i < (LRM_TY + 2) * (LRM_TX + 2); i += 256) {
+        const int ty = i / (LRM_TX + 2), tx = i - ty * (LRM_TX + 2);
+        const int y = min(max(y0 - 1 + ty, 0), H - 1), x = min(max(x0 - 1 + tx, 0), W - 1);     // replicated image border
+        sT[ty][tx] = (short)lr_checked(dispw, d2key, fo + (size_t)y * W, x, W, d12);
+    }
+    __syncthreads();
+    const int tx = t & (LRM_TX - 1), ty = t >> 6;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    int p0 = sT[ty][tx], p1 = sT[ty][tx + 1], p2 = sT[ty][tx + 2], p3 = sT[ty + 1][tx], p4 = sT[ty + 1][tx + 1],
+        p5 = sT[ty + 1][tx + 2], p6 = sT[ty + 2][tx], p7 = sT[ty + 2][tx + 1], p8 = sT[ty + 2][tx + 2];
+    V3D_SORT2(p1, p2); V3D_SORT2(p4, p5); V3D_SORT2(p7, p8); V3D_SORT2(p0, p1);
+    V3D_SORT2(p3, p4); V3D_SORT2(p6, p7); V3D_SORT2(p1, p2); V3D_SORT2(p4, p5);
+    V3D_SORT2(p7, p8); V3D_SORT2(p0, p3); V3D_SORT2(p5, p8); V3D_SORT2(p4, p7);
+    V3D_SORT2(p3, p6); V3D_SORT2(p1, p4); V3D_SORT2(p2, p5); V3D_SORT2(p4, p7);
+    V3D_SORT2(p4, p2); V3D_SORT2(p6, p4); V3D_SORT2(p4, p2);
+    out[fo + (size_t)y * W + x] = (int16_t)p4;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a-8: filterSpeckles as run-based connected-component labelling.  Components are the 4-connected
 // sets of valid pixels joined where |a - b| <= maxDiff; components of at most maxSpeckleSize pixels
 // are invalidated.  (1) every row is cut into horizontal runs by a block-wide scan (no atomics);
@@ -1181,13 +1229,14 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         launch_chain<true, -1, false, 2>(h, a, st);     // r4: (x+1, y), + WTA tail
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_LRCHECK, st);
-    int16_t* raw = (last_stage == 2) ? out : h->raw;
-    hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, raw);
-    V3D_LAUNCH_CHECK();
+    if (last_stage == 2) {
+        hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, out);
+        V3D_LAUNCH_CHECK();
+        prof_mark(h, ST_MEDIAN, st);
+        return V3D_OK;
+    }
     prof_mark(h, ST_MEDIAN, st);
-    if (last_stage == 2) return V3D_OK;
-
-    hipLaunchKernelGGL(k_median3x3, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, raw, W, H, out);
+    hipLaunchKernelGGL(k_lrcheck_median, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, out);
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_SPECKLE, st);
     if (h->prm.speckleWindowSize > 0) {
