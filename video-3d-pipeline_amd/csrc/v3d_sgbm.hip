@@ -272,6 +272,21 @@ __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t
     return pk_add(m1 | (m1 << 16), P2pk);
 }
 
+// delta = min_d L[d] + P2 (both halves) recomputed from a path-state vector: lets checkpoints drop the delta word
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t chain_delta(const uint32_t (&p)[NP], uint32_t P2pk)
+{
+    uint32_t mn = p[0];
+#pragma unroll
+    for (int i = 1; i < NP; i++) mn = pk_min(mn, p[i]);
+    uint32_t m1 = min(mn & 0xFFFFu, mn >> 16);
+    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(1, 0, 3, 2)>(m1));
+    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(2, 3, 0, 1)>(m1));
+    if (LPP >= 8) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_HALF_MIRROR>(m1));
+    if (LPP >= 16) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_MIRROR>(m1));
+    return pk_add(m1 | (m1 << 16), P2pk);
+}
+
 #define WTA_ROWB 144   // bytes per pixel row in LDS (128 + 16 pad, keeps 16-B alignment)
 
 // winner-take-all for one pixel whose 64 aggregated costs sit in LDS (stereosgbm.cpp per-row tail)
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     const int16_t* Crow = a.C + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
     const int16_t* Srow = a.S + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
     const int nblk = (W1 + K - 1) / K;
-    uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * (NP + 1) * 64 + lane;   // [blk][reg][lane]
+    uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;         // [blk][reg][lane]; delta is recomputed
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
     const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
@@ -491,10 +506,9 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 #pragma unroll
                 for (int i = 0; i < NP; i++) p[i] = L[i];
             }
-            uint32_t* c = ck + (size_t)(xb / K + 1) * (NP + 1) * 64;
+            uint32_t* c = ck + (size_t)(xb / K + 1) * NP * 64;
 #pragma unroll
             for (int i = 0; i < NP; i++) c[i * 64] = p[i];
-            c[NP * 64] = delta;
         }
     }
 
@@ -519,10 +533,10 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 #pragma unroll
         for (int i = 0; i < NP; i++) p[i] = 0;
         if (blk > 0) {
-            const uint32_t* c = ck + (size_t)blk * (NP + 1) * 64;
+            const uint32_t* c = ck + (size_t)blk * NP * 64;
 #pragma unroll
             for (int i = 0; i < NP; i++) p[i] = c[i * 64];
-            delta = c[NP * 64];
+            delta = chain_delta<NP, LPP>(p, P2pk);
         }
         uint32_t L0[K][NP];
 #pragma unroll
