@@ -6,7 +6,7 @@
 // direction), a-6 the WTA tail of the last k_chain, a-7 k_lrcheck, a-8 k_median3x3 + k_ccl_*.
 //
 // HBM layout (per frame, W1 = W - 64):
-//   rec1, rec2 : uint2 [H][W]        pre-filter records {grad, grad_lo, grad_hi, raw | raw_lo, raw_hi}
+//   rec        : uint4 [H][W]        pre-filter records, left then right image: {grad, grad_lo, grad_hi, 0 | raw, raw_lo, raw_hi, 0}
 //   C, S       : int16 [H][W1][64]   d fastest: one pixel = one 128-B line
 //   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
 #include "v3d_common.h"
@@ -28,7 +28,7 @@ __device__ __forceinline__ int pf_raw(const uint8_t* r0, int x, int W, int ft)
 
 __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2,
                                                    int W, int H, int pitch, size_t frame_stride, int ft,
-                                                   uint2* __restrict__ rec1, uint2* __restrict__ rec2)
+                                                   uint4* __restrict__ rec)
 {
     // one thread = one pixel; gradient/raw values are computed once and the x+-1 neighbours needed for the
     // half-sample intervals come from LDS (block covers 254 output pixels + 1 halo each side)
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ i
     }
     __syncthreads();
     if (t == 0 || t == 255 || x >= W) return;
+    uint32_t out[4];
 #pragma unroll
     for (int im = 0; im < 2; im++) {
         const int lo = sGR[im][t - 1], hi = sGR[im][t + 1];
@@ -57,25 +58,32 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ i
         if (x < W - 1) { gr = (g[im] + (hi & 0xFF)) >> 1; rr = (r[im] + (hi >> 8)) >> 1; }
         const int g0 = min(min(gl, gr), g[im]), g1 = max(max(gl, gr), g[im]);
         const int q0 = min(min(rl, rr), r[im]), q1 = max(max(rl, rr), r[im]);
-        uint2 rec;
-        rec.x = (uint32_t)g[im] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r[im] << 24);
-        rec.y = (uint32_t)q0 | ((uint32_t)q1 << 8);
-        (im ? rec2 : rec1)[((size_t)f * H + y) * W + x] = rec;
+        out[2 * im] = (uint32_t)g[im] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16);
+        out[2 * im + 1] = (uint32_t)r[im] | ((uint32_t)q0 << 8) | ((uint32_t)q1 << 16);
     }
+    rec[((size_t)f * H + y) * W + x] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// a-4 (ii,iii): BT pixel cost + 5x5 box sum -> C.  One workgroup = a strip of 28 output columns
-// (+2 halo each side) marching down a band of rows; lane = (column, 4 disparities).
+// a-4 (ii,iii): BT pixel cost + 5x5 box sum -> C.  One workgroup = a strip of 60 output columns
+// (+2 halo each side) marching down a band of rows; lane = (column, 8 disparities).
 // Per row: BT cost bytes -> LDS row, 5-tap horizontal sum from LDS, 5-row vertical sum in registers.
 // ------------------------------------------------------------------------------------------------
 template <int NP, int LPP>
 __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t delta, const uint32_t (&c)[NP],
                                                uint32_t (&L)[NP], uint32_t P1pk, uint32_t P2pk, bool first_lane, bool last_lane);
 
-#define COST_COLS 32
-#define COST_OUT 28
-#define COST_NREC 96
+// strip geometry for LPC lanes per column (each lane owns 64/LPC disparities): 512 threads = 512/LPC columns,
+// two halo columns each side; the right image needs 64 more staged records than the left
+template <int LPC> struct CostGeo {
+    static constexpr int EP = 64 / LPC, NP = EP / 2, COLS = 512 / LPC, OUT = COLS - 4, NREC = COLS + 64;
+};
+#ifndef V3D_COST_LPC
+#define V3D_COST_LPC 8
+#endif
+#ifndef V3D_COST_DBG
+#define V3D_COST_DBG 0          // experiment builds only: 1 no right-plane reads, 2 no hsum reads, 4 no staging writes, 8 no left reads
+#endif
 
 __device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
 {
@@ -85,124 +93,152 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1
     const uint32_t b = pk_max(pk_subu_sat(V, U1), pk_subu_sat(U0, V));
     return pk_min(a, b);
 }
-__device__ __forceinline__ uint32_t byte2(uint32_t a, int sa, uint32_t b, int sb)
-{
-    return ((a >> sa) & 0xFFu) | (((b >> sb) & 0xFFu) << 16);
-}
 
-// FUSE_V: the band is the whole image and the vertical SGM path r2 = (x, y-1) rides along: the lane
-// layout (16 lanes x 4 disparities per pixel = one DPP row) is exactly k_chain's DPL = 4 mapping, so
-// C goes from registers straight into chain_step and S = L_r2 is written next to C (saves one full
-// read of C and a launch).
-template <bool FUSE_V>
-__global__ __launch_bounds__(512) void k_cost(const uint2* __restrict__ rec1, const uint2* __restrict__ rec2,
-                                              int W, int H, int W1, int band_h, int P1, int P2, int16_t* __restrict__ C,
-                                              int16_t* __restrict__ S)
+template <int DPL> struct VecT;
+template <> struct VecT<8> { typedef uint4 type; };
+template <> struct VecT<4> { typedef uint2 type; };
+template <int NP> __device__ __forceinline__ void vec_unpack(const uint4& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+template <int NP> __device__ __forceinline__ void vec_unpack(const uint2& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; }
+__device__ __forceinline__ uint4 vec_pack4(const uint32_t (&r)[4]) { return make_uint4(r[0], r[1], r[2], r[3]); }
+__device__ __forceinline__ uint2 vec_pack2(const uint32_t (&r)[2]) { return make_uint2(r[0], r[1]); }
+template <int NP> struct Packer;
+template <> struct Packer<4> { static __device__ __forceinline__ uint4 go(const uint32_t (&r)[4]) { return vec_pack4(r); } };
+template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const uint32_t (&r)[2]) { return vec_pack2(r); } };
+
+// (Tried and dropped: letting the vertical SGM path ride along in this kernel -- the lane layout is k_chain's,
+// but the unbanded kernel it needs has too few waves to gain anything.)
+template <int LPC>
+__global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
+                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C)
 {
+    typedef CostGeo<LPC> G;
+    constexpr int EP = G::EP, NP = G::NP, COLS = G::COLS, OUT = G::OUT, NREC = G::NREC;
+    typedef typename VecT<EP>::type vec_t;
     // right-image planes of one row, per quantity, as REVERSED u16 arrays (index grows with d) in two
     // alignments (copy 1 is copy 0 shifted by one element) so that the packed pair (d, d+1) is always an
     // aligned dword: no byte extraction in the hot loop.  Left-image values are stored pre-broadcast.
-    __shared__ __attribute__((aligned(8))) unsigned short sRV[2][2][6][COST_NREC + 4];
-    __shared__ __attribute__((aligned(8))) uint32_t sUL[2][COST_COLS][6];
-    __shared__ uint2 sPix[2][COST_COLS][16];                    // BT cost of 4 disparities as two packed u16 pairs
+    // RCOPY (dwords between the copies) = 3 (mod 4) at LPC 8 / = 0 (mod 4) at LPC 16: the columns of one 32-lane
+    // ds_read2_b32 group then fall on distinct LDS bank residues (measured: 48 -> 0 conflict cycles per wave-row).
+    constexpr int RROW = (NREC + 4) / 2, RCOPY = 6 * RROW + (LPC == 8 ? 3 : 0), RBUF = 2 * RCOPY;
+    __shared__ __attribute__((aligned(8))) uint32_t sRV[2 * RBUF];
+    __shared__ __attribute__((aligned(8))) uint32_t sUL[2][COLS][6];
+    __shared__ vec_t sPix[2][COLS][LPC];                        // BT cost of EP disparities as packed u16 pairs
 
-    const int tid = threadIdx.x, col = tid >> 4, dq = tid & 15;
-    const int xr0 = blockIdx.x * COST_OUT;
+    const int tid = threadIdx.x, col = tid / LPC, dq = tid % LPC;
+    const int xr0 = blockIdx.x * OUT;
     const int ys = blockIdx.y * band_h, ye = min(ys + band_h, H);
     const int f = blockIdx.z;
-    const uint2* r1 = rec1 + (size_t)f * H * W;
-    const uint2* r2 = rec2 + (size_t)f * H * W;
+    const uint32_t* rf = reinterpret_cast<const uint32_t*>(rec + (size_t)f * H * W);   // 4 dwords per pixel
     int16_t* Cf = C + (size_t)f * H * W1 * V3D_D;
 
     const int xrc = min(max(xr0 - 2 + col, 0), W1 - 1);        // clamped cost-region column of this lane
-    // staged record i <-> image column xr0 - 1 + i; reversed element k = 95 - i.  d = 4dq + j reads record
-    // i0 - j with i0 = xrc - xr0 + 65 - 4dq, i.e. reversed elements k0 + j, k0 = 30 - (xrc - xr0) + 4dq.
-    const int k0 = 30 - (xrc - xr0) + 4 * dq;
+    // staged record i <-> image column xr0 - 1 + i; reversed element k = NREC-1 - i.  d = EP*dq + j reads record
+    // i0 - j with i0 = xrc - xr0 + 65 - EP*dq, i.e. reversed elements k0 + j, k0 = NREC-66 - (xrc - xr0) + EP*dq.
+    const int k0 = NREC - 66 - (xrc - xr0) + EP * dq;
     const int rcopy = k0 & 1, rk = k0 - rcopy;                  // even element offset inside copy `rcopy`
-    const bool out_col = (col >= 2) && (col < 2 + COST_OUT) && (xr0 - 2 + col < W1);
+    const int rv_off = rcopy * RCOPY + rk / 2;                  // dword offset of this lane's first pair (quantity 0, buffer 0)
+    const bool out_col = (col >= 2) && (col < 2 + OUT) && (xr0 - 2 + col < W1);
     const int nrows = (ye - ys) + 4;
 
-    // which record this thread stages per row (threads 0..95: right image, 96..127: left image).
-    // Records are fetched three rows ahead of their use so the wait for row k+1's record can leave the
-    // youngest loads and the C stores of the last rows in flight (vmcnt counts stores too on CDNA).
+    // Staging, spread over six of the eight waves (the workgroup moves at the pace of its slowest wave): a thread
+    // owns HALF a record (dword 0 = gradient triple, dword 1 = raw triple).  Right image, threads 0..2*NREC-1:
+    // record i and its left neighbour i-1 give the packed pair (element k, k+1) of three quantities with one
+    // v_perm_b32 each, written as ONE dword to copy (k & 1) -- together the threads fill both copies.  Left
+    // image, threads 256..256+2*COLS-1: three pre-broadcast dwords.  Records are fetched two rows ahead of
+    // their use so the wait for row k+1's record can leave the youngest loads and the C stores of the last rows
+    // in flight (vmcnt counts stores too on CDNA).
     // (A dedicated 9th staging wave was tried: 576-thread blocks drop a workgroup per CU and lose.)
-    int ld_x = 0; const uint2* ld_src = nullptr;
-    const bool ld_right = tid < COST_NREC, ld_left = tid >= COST_NREC && tid < COST_NREC + COST_COLS;
-    if (ld_right) { ld_x = min(max(xr0 - 1 + tid, 0), W - 1); ld_src = r2; }
-    else if (ld_left) { ld_x = min(max(xr0 - 2 + (tid - COST_NREC), 0), W1 - 1) + V3D_D; ld_src = r1; }
-    auto stage = [&](int b, uint2 rec) {
-        const uint32_t q[6] = { rec.x & 0xFFu, (rec.x >> 8) & 0xFFu, (rec.x >> 16) & 0xFFu, rec.x >> 24, rec.y & 0xFFu, (rec.y >> 8) & 0xFFu };
+    const int half = tid & 1, ri = tid >> 1, lt = (tid - 256) >> 1;
+    const bool ld_right = ri < NREC, ld_left = tid >= 256 && lt < COLS;
+    uint32_t ld_a = 0, ld_b = 0;                                // dword offsets inside a record row (uniform row base + these)
+    int st_off = 0;                                             // dword offset of this thread's staging writes (buffer 0)
+    if (ld_right) {
+        ld_a = 4 * min(max(xr0 - 1 + ri, 0), W - 1) + 2 + half;
+        ld_b = 4 * min(max(xr0 - 2 + ri, 0), W - 1) + 2 + half;
+        const int k = NREC - 1 - ri;
+        st_off = (k & 1) * RCOPY + 3 * half * RROW + (k >> 1);
+    } else if (ld_left) {
+        ld_a = ld_b = 4 * (min(max(xr0 - 2 + lt, 0), W1 - 1) + V3D_D) + half;
+        st_off = lt * 6 + 3 * half;
+    }
+    const bool ld_any = ld_right || ld_left;
+    auto stage = [&](int b, uint2 rec) {                        // rec.x = own half-record, rec.y = left neighbour's
         if (ld_right) {
-            const int k = COST_NREC - 1 - tid;
 #pragma unroll
-            for (int i = 0; i < 6; i++) { sRV[b][0][i][k] = (unsigned short)q[i]; if (k > 0) sRV[b][1][i][k - 1] = (unsigned short)q[i]; }
+            for (int j = 0; j < 3; j++)
+                sRV[b * RBUF + st_off + j * RROW] = __builtin_amdgcn_perm(rec.y, rec.x, 0x0c000c00u | (uint32_t)j | ((uint32_t)(4 + j) << 16));
         } else if (ld_left) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) sUL[b][tid - COST_NREC][i] = q[i] * 0x00010001u;
+            for (int j = 0; j < 3; j++)
+                (&sUL[b][0][0])[st_off + j] = __builtin_amdgcn_perm(rec.x, rec.x, 0x0c000c00u | (uint32_t)j | ((uint32_t)j << 16));
         }
     };
     auto fetch = [&](int k) -> uint2 {
-        return ld_src ? ld_src[(size_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W + ld_x] : make_uint2(0, 0);
+        if (!ld_any) return make_uint2(0, 0);
+        const uint32_t* row = rf + (size_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 4;
+        return make_uint2(row[ld_a], row[ld_b]);
     };
-    if (ld_src) stage(0, fetch(0));
-    uint2 n1 = fetch(1), n2 = fetch(2), n3 = fetch(3);
+    if (ld_any) stage(0, fetch(0));
+    uint2 n1 = fetch(1), n2 = fetch(2);
     __syncthreads();
 
-    uint32_t ring[5][2], vs01 = 0u, vs23 = 0u;                  // last five rows' horizontal sums + their running sum
+    uint32_t ring[5][NP], vs[NP];                               // last five rows' horizontal sums + their running sum
 #pragma unroll
-    for (int i = 0; i < 5; i++) ring[i][0] = ring[i][1] = 0u;
-    const uint32_t P2pk = pk_bcast(P2), P1pk = pk_bcast(P1);
-    uint32_t vp[2] = { 0u, 0u }, vdelta = P2pk;                 // vertical path state (FUSE_V)
-    int16_t* Sf = FUSE_V ? S + (size_t)f * H * W1 * V3D_D : nullptr;
+    for (int j = 0; j < NP; j++) { vs[j] = 0u;
+#pragma unroll
+        for (int i = 0; i < 5; i++) ring[i][j] = 0u; }
+    const uint32_t P2pk = pk_bcast(P2);
 
-    for (int k5 = 0; k5 < nrows; k5 += 5) {
+    for (int k10 = 0; k10 < nrows; k10 += 10) {
 #pragma unroll
-      for (int slot = 0; slot < 5; slot++) {                    // the ring slot is a compile-time index: no register shifts
-        const int k = k5 + slot;
+      for (int s10 = 0; s10 < 10; s10++) {                      // ring slot and LDS buffer are compile-time: no register
+        const int k = k10 + s10;                                // shifts, every LDS address is base + immediate
         if (k >= nrows) break;                                  // uniform
-        const int buf = k & 1;
-        const uint2 n4 = fetch(k + 4);
+        const int slot = s10 % 5, buf = s10 & 1;
+        const uint2 n3 = fetch(k + 3);
 
-        // ---- BT cost of (xrc, d = 4dq .. 4dq+3) on row clamp(ys - 2 + k): quantities g, g_lo, g_hi, r, r_lo, r_hi ----
-        uint32_t U[6], V01[6], V23[6];
+        // ---- BT cost of (xrc, d = EP*dq .. +EP-1) on row clamp(ys - 2 + k): quantities g, g_lo, g_hi, r, r_lo, r_hi ----
+        uint32_t U[6], V[6][NP];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            U[i] = sUL[buf][col][i];
-            const uint32_t* pr = reinterpret_cast<const uint32_t*>(&sRV[buf][rcopy][i][rk]);
-            V01[i] = pr[0]; V23[i] = pr[1];
+            U[i] = (V3D_COST_DBG & 8) ? (uint32_t)(tid + i + k) : sUL[buf][col][i];
+            const uint32_t* pr = &sRV[buf * RBUF + rv_off + i * RROW];
+#pragma unroll
+            for (int j = 0; j < NP; j++) V[i][j] = (V3D_COST_DBG & 1) ? (uint32_t)(tid * 3 + i + j + k) : pr[j];
         }
-        const uint32_t g01 = bt_pair(U[0], U[1], U[2], V01[0], V01[1], V01[2]);
-        const uint32_t r01 = bt_pair(U[3], U[4], U[5], V01[3], V01[4], V01[5]);
-        const uint32_t g23 = bt_pair(U[0], U[1], U[2], V23[0], V23[1], V23[2]);
-        const uint32_t r23 = bt_pair(U[3], U[4], U[5], V23[3], V23[4], V23[5]);
-        const uint32_t p01 = g01 + pk_shr_u(r01, 2), p23 = g23 + pk_shr_u(r23, 2);      // each half <= 93
-        sPix[buf][col][dq] = make_uint2(p01, p23);
+        uint32_t pix[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const uint32_t g = bt_pair(U[0], U[1], U[2], V[0][j], V[1][j], V[2][j]);
+            const uint32_t r = bt_pair(U[3], U[4], U[5], V[3][j], V[4][j], V[5][j]);
+            pix[j] = g + pk_shr_u(r, 2);                        // each half <= 93
+        }
+        sPix[buf][col][dq] = Packer<NP>::go(pix);
 
-        if (k + 1 < nrows && ld_src) stage(buf ^ 1, n1);
-        n1 = n2; n2 = n3; n3 = n4;
+        if (k + 1 < nrows && ld_any && !(V3D_COST_DBG & 4)) stage(buf ^ 1, n1);
+        n1 = n2; n2 = n3;
         __syncthreads();
 
         // ---- 5-tap horizontal sum on packed u16 pairs, 5-row vertical running sum ----
         if (out_col) {
-            const uint2 w0 = sPix[buf][col - 2][dq], w1 = sPix[buf][col - 1][dq], w2 = sPix[buf][col][dq],
-                        w3 = sPix[buf][col + 1][dq], w4 = sPix[buf][col + 2][dq];
-            const uint32_t h01 = w0.x + w1.x + w2.x + w3.x + w4.x;                       // halves <= 5 * 189: no carry
-            const uint32_t h23 = w0.y + w1.y + w2.y + w3.y + w4.y;
-            vs01 += h01 - ring[slot][0]; vs23 += h23 - ring[slot][1];                    // add row k, drop row k - 5
-            ring[slot][0] = h01; ring[slot][1] = h23;
+            uint32_t h[NP], w[NP];
+            vec_unpack<NP>(sPix[buf][col - 2][dq], h);
+#pragma unroll
+            for (int t = -1; t <= 2; t++) {
+                if (V3D_COST_DBG & 2) { for (int j = 0; j < NP; j++) w[j] = h[j] + t; } else
+                vec_unpack<NP>(sPix[buf][col + t][dq], w);
+#pragma unroll
+                for (int j = 0; j < NP; j++) h[j] += w[j];      // halves <= 5 * 189: no carry
+            }
+#pragma unroll
+            for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
             if (k >= 4) {
-                uint2 o;
-                o.x = vs01 + P2pk; o.y = vs23 + P2pk;
+                uint32_t cv[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) cv[j] = vs[j] + P2pk;
                 const int y = ys + k - 4;
-                const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + 4 * dq;
-                if (FUSE_V) *reinterpret_cast<uint2*>(Cf + off) = o; else st_stream(reinterpret_cast<uint2*>(Cf + off), o);
-                if (FUSE_V) {
-                    const uint32_t cv[2] = { o.x, o.y };
-                    uint32_t L[2];
-                    vdelta = chain_step<2, 16>(vp, vdelta, cv, L, P1pk, P2pk, dq == 0, dq == 15);
-                    vp[0] = L[0]; vp[1] = L[1];
-                    *reinterpret_cast<uint2*>(Sf + off) = make_uint2(L[0], L[1]);
-                }
+                const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + EP * dq;
+                st_stream(reinterpret_cast<vec_t*>(Cf + off), Packer<NP>::go(cv));
             }
         }
       }
@@ -227,18 +263,6 @@ struct ChainArgs {
     int16_t* dispw;           // MODE 2: [nframes][H][W]
     uint32_t* d2key;          // MODE 2: [nframes][H][W]
 };
-
-template <int DPL> struct VecT;
-template <> struct VecT<8> { typedef uint4 type; };
-template <> struct VecT<4> { typedef uint2 type; };
-
-template <int NP> __device__ __forceinline__ void vec_unpack(const uint4& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
-template <int NP> __device__ __forceinline__ void vec_unpack(const uint2& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; }
-__device__ __forceinline__ uint4 vec_pack4(const uint32_t (&r)[4]) { return make_uint4(r[0], r[1], r[2], r[3]); }
-__device__ __forceinline__ uint2 vec_pack2(const uint32_t (&r)[2]) { return make_uint2(r[0], r[1]); }
-template <int NP> struct Packer;
-template <> struct Packer<4> { static __device__ __forceinline__ uint4 go(const uint32_t (&r)[4]) { return vec_pack4(r); } };
-template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const uint32_t (&r)[2]) { return vec_pack2(r); } };
 
 // L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta ; returns delta' = min_d L[d] + P2 (both halves)
 template <int NP, int LPP>
@@ -1007,7 +1031,7 @@ struct v3d_sgbm {
     int device, maxW, maxH, maxB;
     int P1, P2, ftzero, uniq, d12;
     int dpl;                                    // disparities per lane in k_chain (4 or 8)
-    uint2 *rec1, *rec2;
+    uint4* rec;
     int16_t *C, *S, *dispw, *raw, *med;
     uint32_t* d2key;
     uint32_t* ckpt;                             // k_hfused checkpoints
@@ -1016,8 +1040,9 @@ struct v3d_sgbm {
     uint32_t vdd_seq;
     int vdd_mode;                               // 0 off, 1 on
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
+    int cost_band;                              // rows per k_cost workgroup
     int vdd_mf4, vdd_mf8;                       // co-residency bound (frames per launch) of each mapping
-    bool hfused, vfused;
+    bool hfused;
     int32_t* labels;
     size_t bytes;
     // optional per-stage HIP-event timing (v3d_sgbm_profile): events live on the caller's stream
@@ -1085,7 +1110,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     const size_t px = (size_t)maxW * maxH * maxB, vol = (size_t)(maxW - V3D_D) * maxH * V3D_D * maxB;
     h->bytes = 0;
     int rc = 0;
-    rc |= ws_alloc(&h->rec1, px, &h->bytes); rc |= ws_alloc(&h->rec2, px, &h->bytes);
+    rc |= ws_alloc(&h->rec, px, &h->bytes);
     rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
     rc |= ws_alloc(&h->dispw, px, &h->bytes); rc |= ws_alloc(&h->raw, px, &h->bytes); rc |= ws_alloc(&h->med, px, &h->bytes);
     rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
@@ -1117,7 +1142,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         h->vdd_mf8 = (b8 * ncu * 9 / 10) / v3d_cdiv(maxW - V3D_D, 128);
         if (h->vdd_mf4 < 1 || h->vdd_mf8 < 1) h->vdd_mode = 0;
     }
-    { const char* e3 = getenv("V3D_VFUSED"); h->vfused = (e3 && atoi(e3) == 1); }   // measured: no gain at batch 8 (the unbanded kernel has too few waves); off
+    { const char* e6 = getenv("V3D_COST_BAND"); h->cost_band = e6 && atoi(e6) >= 8 ? atoi(e6) : 90; }
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
     return V3D_OK;
@@ -1127,7 +1152,7 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = { h->rec1, h->rec2, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt, h->gran, h->vdd_err };
+    void* ptrs[] = { h->rec, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt, h->gran, h->vdd_err };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
@@ -1190,12 +1215,10 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     const int px = W * H;
 
     prof_mark(h, ST_PREFILTER, st);
-    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 254), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec1, h->rec2);
+    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 254), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec);
     prof_mark(h, ST_COST, st);
-    const bool vf = h->vfused && last_stage != 1;
-    if (vf) hipLaunchKernelGGL(k_cost<true>, dim3(v3d_cdiv(W1, COST_OUT), 1, n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, H, h->P1, h->P2, h->C, h->S);
-    else { const int band_h = 136;
-        hipLaunchKernelGGL(k_cost<false>, dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, band_h), n), dim3(512), 0, st, h->rec1, h->rec2, W, H, W1, band_h, h->P1, h->P2, h->C, h->S); }
+    constexpr int COST_OUT = CostGeo<V3D_COST_LPC>::OUT;
+    hipLaunchKernelGGL((k_cost<V3D_COST_LPC>), dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, h->cost_band), n), dim3(512), 0, st, h->rec, W, H, W1, h->cost_band, h->P2, h->C);
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_V2, st);
     if (last_stage == 1) return V3D_OK;
@@ -1205,7 +1228,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     a.dispw = h->dispw; a.d2key = h->d2key;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
-    const bool use_vdd = h->vdd_mode && !vf && H < 4095;
+    const bool use_vdd = h->vdd_mode && H < 4095;
     if (use_vdd) {
         // r1 + r2 + r3 in one lock-step pass (k_vdd); frames per launch bounded by co-residency
         // mapping: 4 disparities per lane (64-column strips) while the whole batch fits one co-resident launch, else
@@ -1214,7 +1237,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         prof_mark(h, ST_D1, st);
         prof_mark(h, ST_D3, st);
     } else {
-    if (!vf) launch_chain<false, 0, false, 0>(h, a, st);    // r2: (x, y-1) (else done inside k_cost)
+    launch_chain<false, 0, false, 0>(h, a, st);         // r2: (x, y-1)
     prof_mark(h, ST_D1, st);
     launch_chain<false, 1, false, 1>(h, a, st);         // r1: (x-1, y-1)
     prof_mark(h, ST_D3, st);

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libv3d_hip.so")
+_LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "libv3d_hip.so")   # override: experiment builds (tools/)
 _lib = None
 
 # every symbol include/v3d_hip.h declares
