@@ -40,6 +40,18 @@ def test_non_integer_scale(native, oracle):
     assert _rel_err(got.astype(np.float64), want).max() <= RTOL
 
 
+@pytest.mark.parametrize("Wg,Hg,r", [(233, 151, 8), (301, 97, 4), (257, 33, 8), (19, 21, 8)])
+def test_odd_guide_sizes(native, oracle, Wg, Hg, r):
+    """odd widths take the marching kernel's scalar-store path (pixel pairs straddle row alignment), odd heights a
+    half-filled last row pair; a guide narrower than the window clips every box"""
+    depth, _ = _case(Wg, 90, 50)
+    rng = np.random.default_rng(Wg * 7 + Hg)
+    guide = rng.integers(0, 256, (Hg, Wg), dtype=np.uint8)
+    want = oracle.guided_upscale(depth, guide, r, 1e-3)
+    got = native.guided_upscale(native.to_device(depth), native.to_device(guide), r, 1e-3).cpu().numpy()
+    assert _rel_err(got.astype(np.float64), want).max() <= RTOL
+
+
 def test_constant_guide_is_double_box_of_p(native, oracle):
     """I const => a = 0, b = box(p), q = box(box(p))   (SURVEY 8c known-answer 11)"""
     depth, _ = _case(9, 80, 50)

@@ -6,12 +6,12 @@
 //   a = cov(I,p) / (var(I) + eps),  b = mean(p) - a*mean(I),  q = mean(a)*I + mean(b)
 // with (2r+1)^2 box means clipped at the image border and divided by the true pixel count.
 //
-// Two sweeps, each one LDS-tiled kernel (64x16 output tile + r halo), box sums separable with
-// register sliding windows.  HBM traffic: sweep 1 reads guide + depth_lo tiles, writes a,b;
-// sweep 2 reads a,b tiles + guide, writes q.
-// Numerics: all sums, a and b are float64 (gfx950 runs f64 vector math at half the f32 rate and this
-// kernel is LDS-bound): next to zero-depth regions q is ~1e-4 while the window holds values ~40, and the
-// 1e-3 *relative* parity bar cannot be met there with f32 cancellation in cov/var and in box(b).
+// Two sweeps (k_gfm for r in {4, 8}: column-marching strips; k_gf for other radii: LDS tiles), box sums
+// separable with sliding windows.  HBM traffic: sweep 1 reads guide + depth_lo, writes a,b; sweep 2 reads a,b +
+// guide, writes q.
+// Numerics: all sums, a and b are float64 (full rate per instruction on gfx950, but no packed form): next to
+// zero-depth regions q is ~1e-4 while the window holds values ~40, and the 1e-3 *relative* parity bar cannot be
+// met there with f32 cancellation in cov/var and in box(b).
 #include "v3d_common.h"
 
 // 1/x to full double precision: v_rcp_f64 seed (~26 bits) + two Newton steps (5 instructions instead of the
@@ -149,35 +149,49 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
 
 // ------------------------------------------------------------------------------------------------
 // Fast path for r in {4, 8}: column-marching sweeps.  A workgroup owns a strip of 256 - 2r output
-// columns (+ r halo each side, one thread per column) and marches down a band of rows.  The vertical box
-// sums slide in REGISTERS (a compile-time ring of the last 2r+1 rows' values per column: add the entering
-// row, subtract the leaving one); only the per-row vertical sums cross lanes, through a 2 x NS x 256 f64
-// LDS row buffer, for the 2r+1-tap horizontal sum.  16 KB of LDS per workgroup -> full occupancy, one
-// barrier per row, every input element is read once per band (+ 2r warm-up rows).
+// columns (+ r halo each side, one thread per column) and marches down a band of rows, TWO rows per step.
+// The vertical box sums slide in REGISTERS (a compile-time ring of the last 2r+1 rows' values per column:
+// add the entering row, subtract the leaving one); only the per-row vertical sums cross lanes, through a
+// double-buffered LDS row pair, for the 2r+1-tap horizontal sum.  In that phase a thread owns a PAIR of adjacent
+// output pixels of one of the two rows: their windows share 2r of 2r+1 columns, so 2r+2 values -- r+1 aligned
+// 16-byte LDS reads per quantity -- and 2r+1 adds serve both (half the adds, and ds_read_b128 moves 256 B/clk
+// where the ds_read2_b64 pairs the compiler forms from single f64 reads move 128: measured, the one-pixel-per-
+// thread version spent 72 % of its time in the LDS pipe).  One barrier per two rows, every input element is read
+// once per band (+ 2r warm-up rows), a/b/out leave as 16/16/8-byte stores.
 // ------------------------------------------------------------------------------------------------
+typedef double v3d_f64x2 __attribute__((ext_vector_type(2)));
+typedef float v3d_f32x2 __attribute__((ext_vector_type(2)));
+
 template <int SWEEP, int RR>
 __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo, int Wlo, int Hlo,
                                              const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
                                              double* __restrict__ A, double* __restrict__ B, float* __restrict__ out,
                                              size_t depth_stride, size_t guide_stride)
 {
-    constexpr int R = 2 * RR + 1;
+    static_assert(RR % 2 == 0, "pairs must not straddle the strip's halo boundary");
+    constexpr int R = 2 * RR + 1, NOUT = 256 - 2 * RR;
     // sweep 1 sums {g, g*g} as exact int32 (the guide is 8-bit: sum(I) = sum(g)/255, sum(I*I) = sum(g*g)/255^2) and
     // {p, g*p} in f64; sweep 2 sums {a, b} in f64
-    __shared__ double sVd[2][2][256];
-    __shared__ int sVi[2][2][256];
+    __shared__ __attribute__((aligned(16))) double sVd[2][2][2][256];       // [buffer][row of the pair][quantity][column]
+    __shared__ __attribute__((aligned(16))) int2 sVi[2][2][256];            // [buffer][row][column] {sum g, sum g*g}
     {   // frame of the batch
         const size_t f = blockIdx.z, n4 = (size_t)W * H;
         depth_lo += f * depth_stride; guide += f * guide_stride; A += f * 2 * n4; B += f * 2 * n4; out += f * n4;
     }
     const int tid = threadIdx.x;
-    const int gx = blockIdx.x * (256 - 2 * RR) - RR + tid;          // this thread's image column
+    const int gx = blockIdx.x * NOUT - RR + tid;                    // vertical phase: this thread's image column
     const int ya = blockIdx.y * band_h, yb = min(ya + band_h, H);
     const bool col_ok = gx >= 0 && gx < W;
-    const bool out_col = tid >= RR && tid < 256 - RR && gx < W;
     const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
-    const int cx = min(gx + RR, W - 1) - max(gx - RR, 0) + 1;
     const int nsteps = (yb - ya) + 2 * RR;
+
+    // horizontal phase: row hrow of the step's pair, output pixels (hgx, hgx + 1)
+    const int hrow = tid >> 7, hq = tid & 127;
+    const int hgx = blockIdx.x * NOUT - RR + 2 * hq;
+    const bool pair_in = 2 * hq >= RR && 2 * hq < 256 - RR;
+    const bool px0 = pair_in && hgx < W, px1 = pair_in && hgx + 1 < W;
+    const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
+    const bool vec_ok = px1 && (W & 1) == 0;                        // both pixels in the image and rows pair-aligned
 
     // bilinear source coordinates are separable: the x part is a per-thread constant, the y part per row
     int bxa = 0, bxb = 0; double bwx = 0.0;
@@ -191,62 +205,148 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
 #pragma unroll
     for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; rg[j] = 0; }
 
-    for (int t0 = 0; t0 < nsteps; t0 += R) {
+    // inputs of the two rows a step consumes, fetched one step ahead (the loads of step s+1 fly during step s)
+    // (loads are UNCONDITIONAL, from clamped addresses, and the out-of-image case is a select afterwards: behind a
+    //  branch the compiler's s_waitcnt model can no longer count them and waits for the prefetch it just issued)
+    struct RowIn { int g; float a0, a1, b0, b1; double n0, n1; bool in; };
+    const int gxc = min(max(gx, 0), W - 1);
+    auto fetch_row = [&](int t) -> RowIn {
+        RowIn q; q.g = 0; q.a0 = q.a1 = q.b0 = q.b1 = 0.f; q.n0 = q.n1 = 0.0;
+        const int e = ya - RR + t;                                       // row entering the window
+        q.in = col_ok && e >= 0 && e < H && t < nsteps;
+        const size_t o = (size_t)min(max(e, 0), H - 1) * W + gxc;
+        if (SWEEP == 1) {
+            q.g = guide[o];
+            const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy);
+            const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
+            const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
+            q.a0 = ra[bxa]; q.a1 = ra[bxb]; q.b0 = rb[bxa]; q.b1 = rb[bxb];
+        } else {
+            q.n0 = __builtin_nontemporal_load(A + o); q.n1 = __builtin_nontemporal_load(B + o);
+        }
+        return q;
+    };
+    RowIn nx[2] = { fetch_row(0), fetch_row(1) };
+
+    int buf = 0;
+    for (int t0 = 0; t0 < nsteps; t0 += 2 * R) {
 #pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int t = t0 + j;
-            if (t < nsteps) {                                        // uniform
-                const int e = ya - RR + t;                           // row entering the window
-                const bool in = col_ok && e >= 0 && e < H;
-                if (SWEEP == 1) {
-                    int gn = 0; double pn = 0.0;
-                    if (in) {
-                        gn = guide[(size_t)e * W + gx];
-                        const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy), wy = fy - y0f;
-                        const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
-                        const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
-                        const double top = (double)ra[bxa] * (1.0 - bwx) + (double)ra[bxb] * bwx;
-                        const double bot = (double)rb[bxa] * (1.0 - bwx) + (double)rb[bxb] * bwx;
-                        pn = top * (1.0 - wy) + bot * wy;
+        for (int s = 0; s < R; s++) {
+            const int tA = t0 + 2 * s;
+            if (tA < nsteps) {                                           // uniform
+                const int y0 = ya - 2 * RR + tA;                         // output row completed by the first row of the pair
+                const bool emit = y0 >= ya;                              // uniform (2*RR is even: pairs never straddle ya)
+                const RowIn cur[2] = { nx[0], nx[1] };
+                nx[0] = fetch_row(tA + 2); nx[1] = fetch_row(tA + 3);
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int j = (2 * s + rr) % R;                      // compile-time ring slot
+                    if (SWEEP == 1) {
+                        int gn = 0; double pn = 0.0;
+                        if (cur[rr].in) {
+                            gn = cur[rr].g;
+                            const int e = ya - RR + tA + rr;
+                            const double fy = (e + 0.5) * sy - 0.5, wy = fy - floor(fy);
+                            const double top = (double)cur[rr].a0 * (1.0 - bwx) + (double)cur[rr].a1 * bwx;
+                            const double bot = (double)cur[rr].b0 * (1.0 - bwx) + (double)cur[rr].b1 * bwx;
+                            pn = top * (1.0 - wy) + bot * wy;
+                        }
+                        const int go = rg[j]; const double po = r1[j];   // row e - R leaves (zeros during warm-up)
+                        rg[j] = gn; r1[j] = pn;
+                        vg += gn - go; vgg += gn * gn - go * go;
+                        v0 += pn - po; v1 += (double)gn * pn - (double)go * po;
+                    } else {
+                        const double n0 = cur[rr].in ? cur[rr].n0 : 0.0, n1 = cur[rr].in ? cur[rr].n1 : 0.0;
+                        const double o0 = r0[j], o1 = r1[j];
+                        r0[j] = n0; r1[j] = n1;
+                        v0 += n0 - o0; v1 += n1 - o1;
                     }
-                    const int go = rg[j]; const double po = r1[j];   // row e - R leaves (zeros during warm-up)
-                    rg[j] = gn; r1[j] = pn;
-                    vg += gn - go; vgg += gn * gn - go * go;
-                    v0 += pn - po; v1 += (double)gn * pn - (double)go * po;
-                } else {
-                    double n0 = 0.0, n1 = 0.0;
-                    if (in) { n0 = __builtin_nontemporal_load(A + (size_t)e * W + gx); n1 = __builtin_nontemporal_load(B + (size_t)e * W + gx); }
-                    const double o0 = r0[j], o1 = r1[j];
-                    r0[j] = n0; r1[j] = n1;
-                    v0 += n0 - o0; v1 += n1 - o1;
+                    if (emit) {
+                        sVd[buf][rr][0][tid] = v0; sVd[buf][rr][1][tid] = v1;
+                        if (SWEEP == 1) sVi[buf][rr][tid] = make_int2(vg, vgg);
+                    }
                 }
-                const int y = e - RR;                                // output row whose window is now complete
-                if (y >= ya) {                                       // uniform
-                    const int buf = t & 1;
-                    sVd[buf][0][tid] = v0; sVd[buf][1][tid] = v1;
-                    if (SWEEP == 1) { sVi[buf][0][tid] = vg; sVi[buf][1][tid] = vgg; }
+                if (emit) {
                     __syncthreads();
-                    if (out_col) {
-                        double s0 = 0.0, s1 = 0.0; int sg = 0, sgg = 0;
+                    const int y = y0 + hrow;
+                    if (px0 && y < yb) {
+                        // 2r+2 columns hgx-r .. hgx+1+r: the inner 2r are common to both pixels' windows.  Reads go out plane
+                        // by plane in groups of three, fenced for the scheduler: all of them at once would hold 100+ registers
+                        double fq[2], lq[2], cq[2];                       // per plane: first / last column, common part
 #pragma unroll
-                        for (int k = -RR; k <= RR; k++) {
-                            s0 += sVd[buf][0][tid + k]; s1 += sVd[buf][1][tid + k];
-                            if (SWEEP == 1) { sg += sVi[buf][0][tid + k]; sgg += sVi[buf][1][tid + k]; }
+                        for (int q = 0; q < 2; q++) {
+                            const v3d_f64x2* d = reinterpret_cast<const v3d_f64x2*>(&sVd[buf][hrow][q][0]) + (hq - RR / 2);
+                            double f = 0.0, l = 0.0, c = 0.0;
+#pragma unroll
+                            for (int ch = 0; ch <= RR; ch += 3) {
+                                v3d_f64x2 w[3];
+#pragma unroll
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) w[i] = d[ch + i];
+#pragma unroll
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) {
+                                    if (ch + i == 0) { f = w[i].x; c = w[i].y; }
+                                    else if (ch + i == RR) { c += w[i].x; l = w[i].y; }
+                                    else { c += w[i].x; c += w[i].y; }
+                                }
+                                asm volatile("" : "+v"(c) :: "memory");   // operand: the chunk's adds cannot sink below the next chunk's reads
+                            }
+                            fq[q] = f; lq[q] = l; cq[q] = c;
                         }
-                        const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
-                        const double inv = gf_rcp((double)(cx * cy));
+                        int g0 = 0, gg0 = 0, gl = 0, ggl = 0, cg = 0, cgg = 0;
                         if (SWEEP == 1) {
-                            const double mI = (double)sg * (inv * (1.0 / 255.0)), mp = s0 * inv;
-                            const double mII = (double)sgg * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
-                            const double var = mII - mI * mI, cov = mIp - mI * mp;
-                            const double a = cov * gf_rcp(var + eps);
-                            __builtin_nontemporal_store(a, A + (size_t)y * W + gx);
-                            __builtin_nontemporal_store(mp - a * mI, B + (size_t)y * W + gx);
+                            const int4* gi = reinterpret_cast<const int4*>(&sVi[buf][hrow][0]) + (hq - RR / 2);
+#pragma unroll
+                            for (int ch = 0; ch <= RR; ch += 3) {
+                                int4 u[3];
+#pragma unroll
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) u[i] = gi[ch + i];
+#pragma unroll
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) {
+                                    if (ch + i == 0) { g0 = u[i].x; gg0 = u[i].y; cg = u[i].z; cgg = u[i].w; }
+                                    else if (ch + i == RR) { cg += u[i].x; cgg += u[i].y; gl = u[i].z; ggl = u[i].w; }
+                                    else { cg += u[i].x + u[i].z; cgg += u[i].y + u[i].w; }
+                                }
+                                asm volatile("" : "+v"(cg), "+v"(cgg) :: "memory");
+                            }
+                        }
+                        const double s0a = cq[0] + fq[0], s0b = cq[0] + lq[0], s1a = cq[1] + fq[1], s1b = cq[1] + lq[1];
+                        const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                        const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
+                        const size_t o = (size_t)y * W + hgx;
+                        if (SWEEP == 1) {
+                            const int sga = cg + g0, sgb = cg + gl, sgga = cgg + gg0, sggb = cgg + ggl;
+                            double ab[2][2];
+#pragma unroll
+                            for (int n = 0; n < 2; n++) {
+                                const double inv = n ? invb : inva;
+                                const double mI = (double)(n ? sgb : sga) * (inv * (1.0 / 255.0)), mp = (n ? s0b : s0a) * inv;
+                                const double mII = (double)(n ? sggb : sgga) * (inv * (1.0 / 65025.0)), mIp = (n ? s1b : s1a) * (inv * (1.0 / 255.0));
+                                const double var = mII - mI * mI, cov = mIp - mI * mp;
+                                const double a = cov * gf_rcp(var + eps);
+                                ab[n][0] = a; ab[n][1] = mp - a * mI;
+                            }
+                            if (vec_ok) {
+                                v3d_f64x2 va = { ab[0][0], ab[1][0] }, vb = { ab[0][1], ab[1][1] };
+                                __builtin_nontemporal_store(va, reinterpret_cast<v3d_f64x2*>(A + o));
+                                __builtin_nontemporal_store(vb, reinterpret_cast<v3d_f64x2*>(B + o));
+                            } else {
+                                A[o] = ab[0][0]; B[o] = ab[0][1];
+                                if (px1) { A[o + 1] = ab[1][0]; B[o + 1] = ab[1][1]; }
+                            }
                         } else {
-                            const double I = (double)guide[(size_t)y * W + gx] * (1.0 / 255.0);
-                            __builtin_nontemporal_store((float)((s0 * inv) * I + (s1 * inv)), out + (size_t)y * W + gx);
+                            const double Ia = (double)guide[o] * (1.0 / 255.0);
+                            const double Ib = px1 ? (double)guide[o + 1] * (1.0 / 255.0) : 0.0;
+                            const float qa = (float)((s0a * inva) * Ia + (s1a * inva)), qb = (float)((s0b * invb) * Ib + (s1b * invb));
+                            if (vec_ok) {
+                                v3d_f32x2 vq = { qa, qb };
+                                __builtin_nontemporal_store(vq, reinterpret_cast<v3d_f32x2*>(out + o));
+                            } else {
+                                out[o] = qa;
+                                if (px1) out[o + 1] = qb;
+                            }
                         }
                     }
+                    buf ^= 1;
                 }
             }
         }
@@ -257,11 +357,11 @@ template <int RR>
 static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        double* A, double* B, float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
-    // band heights: sweep 1 is f64-compute bound (smaller bands = more workgroups), sweep 2 is bound by its halo'd
-    // re-reads of the f64 a/b planes (taller bands = less halo)
+    // band heights (measured sweep, 30 x 4K frames): each band pays 2r warm-up rows; sweep 1 is VALU-bound, sweep 2
+    // is bound by its re-reads of the f64 a/b planes
     const char* e1 = getenv("V3D_GF_BAND1");
     const char* e2 = getenv("V3D_GF_BAND2");
-    const int band1 = e1 ? atoi(e1) : 40, band2 = e2 ? atoi(e2) : 270;
+    const int band1 = e1 ? atoi(e1) : 90, band2 = e2 ? atoi(e2) : 270;
     const dim3 grid1(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band1), n), grid2(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band2), n);
     hipLaunchKernelGGL((k_gfm<1, RR>), grid1, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band1, A, B, out, depth_stride, guide_stride);
     hipLaunchKernelGGL((k_gfm<2, RR>), grid2, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band2, A, B, out, depth_stride, guide_stride);
