@@ -119,4 +119,26 @@ __device__ __forceinline__ void st_stream(uint2* p, uint2 v)
 #endif
 }
 
+// ---- raw buffer access (range-checked: an offset with bit 31 set is out of range for every buffer this library
+// builds, so a lane is switched off by its OFFSET, not by a branch).  Why it matters on CDNA: vmcnt counts loads
+// AND stores in issue order, and once a VMEM instruction sits behind a branch the compiler's s_waitcnt model
+// must assume it was not issued -- every later wait then degenerates to vmcnt(0) and a prefetch pipeline ends up
+// waiting for the store it has just issued.  Unconditional instructions keep the counts exact.
+#define V3D_BUF_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_load_u32(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+__device__ __forceinline__ void buf_store_stream(__amdgpu_buffer_rsrc_t r, uint32_t off, uint4 v)
+{
+    v3d_u32x4 t = { v.x, v.y, v.z, v.w };
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, V3D_NT ? 2 : 0);
+}
+__device__ __forceinline__ void buf_store_stream(__amdgpu_buffer_rsrc_t r, uint32_t off, uint2 v)
+{
+    v3d_u32x2 t = { v.x, v.y };
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, V3D_NT ? 2 : 0);
+}
+
 #endif

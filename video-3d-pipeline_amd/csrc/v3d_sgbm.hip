@@ -138,6 +138,7 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
     const int rcopy = k0 & 1, rk = k0 - rcopy;                  // even element offset inside copy `rcopy`
     const int rv_off = rcopy * RCOPY + rk / 2;                  // dword offset of this lane's first pair (quantity 0, buffer 0)
     const bool out_col = (col >= 2) && (col < 2 + OUT) && (xr0 - 2 + col < W1);
+    const int hc = min(max(col, 2), COLS - 3);                  // centre of the 5-tap window this lane sums
     const int nrows = (ye - ys) + 4;
 
     // Staging, spread over six of the eight waves (the workgroup moves at the pace of its slowest wave): a thread
@@ -173,10 +174,13 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
                 (&sUL[b][0][0])[st_off + j] = __builtin_amdgcn_perm(rec.x, rec.x, 0x0c000c00u | (uint32_t)j | ((uint32_t)j << 16));
         }
     };
+    // every VMEM instruction of the row loop is issued unconditionally (v3d_common.h: raw buffer access): threads
+    // that stage nothing, halo columns and the warm-up rows are switched off through an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)H * W1 * (V3D_D * 2u));
+    const uint32_t ld_off = ld_any ? 0u : V3D_BUF_OOB;
     auto fetch = [&](int k) -> uint2 {
-        if (!ld_any) return make_uint2(0, 0);
-        const uint32_t* row = rf + (size_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 4;
-        return make_uint2(row[ld_a], row[ld_b]);
+        const uint32_t ro = (uint32_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 16u;
+        return make_uint2(buf_load_u32(rs_rec, (ro + ld_a * 4u) | ld_off), buf_load_u32(rs_rec, (ro + ld_b * 4u) | ld_off));
     };
     if (ld_any) stage(0, fetch(0));
     uint2 n1 = fetch(1), n2 = fetch(2);
@@ -198,20 +202,26 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
         const uint2 n3 = fetch(k + 3);
 
         // ---- BT cost of (xrc, d = EP*dq .. +EP-1) on row clamp(ys - 2 + k): quantities g, g_lo, g_hi, r, r_lo, r_hi ----
-        uint32_t U[6], V[6][NP];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            U[i] = (V3D_COST_DBG & 8) ? (uint32_t)(tid + i + k) : sUL[buf][col][i];
-            const uint32_t* pr = &sRV[buf * RBUF + rv_off + i * RROW];
-#pragma unroll
-            for (int j = 0; j < NP; j++) V[i][j] = (V3D_COST_DBG & 1) ? (uint32_t)(tid * 3 + i + j + k) : pr[j];
-        }
+        // the two planes (gradient, raw) one after the other, fenced: all 6 x NP right-image dwords in flight at once
+        // cost a dozen more registers than the 80 that three workgroups per CU leave
         uint32_t pix[NP];
 #pragma unroll
-        for (int j = 0; j < NP; j++) {
-            const uint32_t g = bt_pair(U[0], U[1], U[2], V[0][j], V[1][j], V[2][j]);
-            const uint32_t r = bt_pair(U[3], U[4], U[5], V[3][j], V[4][j], V[5][j]);
-            pix[j] = g + pk_shr_u(r, 2);                        // each half <= 93
+        for (int pl = 0; pl < 2; pl++) {
+            uint32_t U[3], V[3][NP];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                U[i] = (V3D_COST_DBG & 8) ? (uint32_t)(tid + i + k) : sUL[buf][col][3 * pl + i];
+                const uint32_t* pr = &sRV[buf * RBUF + rv_off + (3 * pl + i) * RROW];
+#pragma unroll
+                for (int j = 0; j < NP; j++) V[i][j] = (V3D_COST_DBG & 1) ? (uint32_t)(tid * 3 + i + j + k) : pr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const uint32_t c = bt_pair(U[0], U[1], U[2], V[0][j], V[1][j], V[2][j]);
+                pix[j] = pl == 0 ? c : pix[j] + pk_shr_u(c, 2);     // gradient + raw / 4; each half <= 93
+            }
+            if (pl == 0) { if (NP == 4) asm volatile("" : "+v"(pix[0]), "+v"(pix[1]), "+v"(pix[NP - 2]), "+v"(pix[NP - 1]) :: "memory");
+                           else asm volatile("" : "+v"(pix[0]), "+v"(pix[NP - 1]) :: "memory"); }
         }
         sPix[buf][col][dq] = Packer<NP>::go(pix);
 
@@ -220,26 +230,23 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
         __syncthreads();
 
         // ---- 5-tap horizontal sum on packed u16 pairs, 5-row vertical running sum ----
-        if (out_col) {
+        {
             uint32_t h[NP], w[NP];
-            vec_unpack<NP>(sPix[buf][col - 2][dq], h);
+            vec_unpack<NP>(sPix[buf][hc - 2][dq], h);               // (halo lanes re-sum a neighbour's window; never stored)
 #pragma unroll
             for (int t = -1; t <= 2; t++) {
                 if (V3D_COST_DBG & 2) { for (int j = 0; j < NP; j++) w[j] = h[j] + t; } else
-                vec_unpack<NP>(sPix[buf][col + t][dq], w);
+                vec_unpack<NP>(sPix[buf][hc + t][dq], w);
 #pragma unroll
                 for (int j = 0; j < NP; j++) h[j] += w[j];      // halves <= 5 * 189: no carry
             }
 #pragma unroll
             for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
-            if (k >= 4) {
-                uint32_t cv[NP];
+            uint32_t cv[NP];
 #pragma unroll
-                for (int j = 0; j < NP; j++) cv[j] = vs[j] + P2pk;
-                const int y = ys + k - 4;
-                const size_t off = ((size_t)y * W1 + (xr0 - 2 + col)) * V3D_D + EP * dq;
-                st_stream(reinterpret_cast<vec_t*>(Cf + off), Packer<NP>::go(cv));
-            }
+            for (int j = 0; j < NP; j++) cv[j] = vs[j] + P2pk;
+            const uint32_t off = (uint32_t)(((ys + k - 4) * W1 + (xr0 - 2 + col)) * V3D_D + EP * dq) * 2u;
+            buf_store_stream(rs_c, (out_col && k >= 4) ? off : V3D_BUF_OOB, Packer<NP>::go(cv));
         }
       }
     }
@@ -1088,7 +1095,9 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     }
     if (prm->mode != V3D_MODE_SGBM && prm->mode != V3D_MODE_HH) { v3d_set_error("unsupported mode %d", prm->mode); return V3D_ERR_UNSUPPORTED; }
     if (maxW <= V3D_D + 4 || maxH < 1 || maxB < 1) { v3d_set_error("bad geometry %dx%d batch %d", maxW, maxH, maxB); return V3D_ERR_ARG; }
-    if ((size_t)maxW * maxH * V3D_D >= ((size_t)1 << 31)) { v3d_set_error("frame too large for 32-bit volume offsets"); return V3D_ERR_UNSUPPORTED; }
+    // one frame's cost volume must stay below 2 GiB: k_cost addresses it through a range-checked buffer whose
+    // out-of-range marker is bit 31 of the byte offset
+    if ((size_t)maxW * maxH * V3D_D >= ((size_t)1 << 30)) { v3d_set_error("frame too large for 31-bit volume byte offsets"); return V3D_ERR_UNSUPPORTED; }
     V3D_HIP_CHECK(hipSetDevice(device));
     v3d_sgbm* h = new v3d_sgbm();
     h->prof_on = false; h->prof_calls = 0;
