@@ -15,53 +15,80 @@
 // ------------------------------------------------------------------------------------------------
 // a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pf_grad(const uint8_t* r0, const uint8_t* ru, const uint8_t* rd, int x, int W, int ft)
-{
-    if (x <= 0 || x >= W - 1) return ft;     // tab[0]
-    int g = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + ((int)ru[x + 1] - (int)ru[x - 1]) + ((int)rd[x + 1] - (int)rd[x - 1]);
-    return min(max(g, -ft), ft) + ft;
-}
-__device__ __forceinline__ int pf_raw(const uint8_t* r0, int x, int W, int ft)
-{
-    return (x <= 0 || x >= W - 1) ? ft : (int)r0[x];
-}
-
+// A workgroup owns 252 output columns (+2 halo each side, one thread per column) and marches down a band of rows:
+// per row a thread loads ONE byte per image (the row entering the 3-row Sobel window), the x+-1 neighbours come
+// from LDS, and the horizontal differences of the two older rows ride along in registers -- 2 byte loads per pixel
+// instead of the 14 a one-row-per-workgroup version issues (that one was bound by its VMEM instruction count).
+// The records trail the gradients by one row so that both LDS exchanges of a step share a single barrier.
+#define PF_BAND 64
 __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2,
                                                    int W, int H, int pitch, size_t frame_stride, int ft,
                                                    uint4* __restrict__ rec)
 {
-    // one thread = one pixel; gradient/raw values are computed once and the x+-1 neighbours needed for the
-    // half-sample intervals come from LDS (block covers 254 output pixels + 1 halo each side)
-    __shared__ unsigned short sGR[2][256];
-    const int t = threadIdx.x;
-    const int x = blockIdx.x * 254 - 1 + t, y = blockIdx.y, f = blockIdx.z;
+    __shared__ uint8_t sI[2][2][256];              // [step parity][image][column] bytes of the entering row
+    __shared__ unsigned short sGR[2][2][256];      // [step parity][image][column] grad | raw << 8 of the row one step back
+    const int t = threadIdx.x, f = blockIdx.z;
+    const int x = blockIdx.x * 252 - 2 + t;        // bytes valid for all t, gradients for t in [1, 254], records for [2, 253]
     const int xc = min(max(x, 0), W - 1);
-    int g[2], r[2];
+    const bool xin = x > 0 && x < W - 1;           // else tab[0] = ft for both planes (OpenCV leaves the border columns at zero gradient)
+    const int ya = blockIdx.y * PF_BAND, yb = min(ya + PF_BAND, H);
+    const uint8_t* I0 = img1 + f * frame_stride + xc;
+    const uint8_t* I1 = img2 + f * frame_stride + xc;
+    auto ld = [&](int y) -> uint32_t {             // both images' bytes of row clamp(y), unconditional loads
+        const size_t o = (size_t)min(max(y, 0), H - 1) * pitch;
+        return (uint32_t)I0[o] | ((uint32_t)I1[o] << 8);
+    };
+    // rows clamp(ya-1) and ya prime the window; their horizontal differences need an exchange each
+    int dm[2], d0[2], r0[2];                       // dh(row y-1), dh(row y), raw(row y) per image
+    {
+        const uint32_t vm = ld(ya - 1), v0 = ld(ya);
+        sI[0][0][t] = (uint8_t)vm; sI[0][1][t] = (uint8_t)(vm >> 8);
+        sI[1][0][t] = (uint8_t)v0; sI[1][1][t] = (uint8_t)(v0 >> 8);
+        __syncthreads();
+        const int tl = max(t - 1, 0), tr = min(t + 1, 255);
 #pragma unroll
-    for (int im = 0; im < 2; im++) {
-        const uint8_t* I = (im ? img2 : img1) + f * frame_stride;
-        const uint8_t* r0 = I + (size_t)y * pitch;
-        const uint8_t* ru = I + (size_t)(y > 0 ? y - 1 : y) * pitch;
-        const uint8_t* rd = I + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
-        g[im] = pf_grad(r0, ru, rd, xc, W, ft);
-        r[im] = pf_raw(r0, xc, W, ft);
-        sGR[im][t] = (unsigned short)(g[im] | (r[im] << 8));
+        for (int im = 0; im < 2; im++) {
+            dm[im] = (int)sI[0][im][tr] - (int)sI[0][im][tl];
+            d0[im] = (int)sI[1][im][tr] - (int)sI[1][im][tl];
+            r0[im] = (v0 >> (8 * im)) & 0xFF;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (t == 0 || t == 255 || x >= W) return;
-    uint32_t out[4];
+    uint32_t nxt = ld(ya + 1);
+    int gp[2] = { 0, 0 }, rp[2] = { 0, 0 };         // grad / raw of the previous row (whose record is still owed)
+    const int tl = max(t - 1, 0), tr = min(t + 1, 255);
+    for (int y = ya; y <= yb; y++) {                // one extra step flushes the last row's record
+        const int par = y & 1;
+        const uint32_t ve = nxt;                    // row clamp(y+1)
+        nxt = ld(y + 2);
+        sI[par][0][t] = (uint8_t)ve; sI[par][1][t] = (uint8_t)(ve >> 8);
+        sGR[par][0][t] = (unsigned short)(gp[0] | (rp[0] << 8));
+        sGR[par][1][t] = (unsigned short)(gp[1] | (rp[1] << 8));
+        __syncthreads();
+        uint32_t out[4];
 #pragma unroll
-    for (int im = 0; im < 2; im++) {
-        const int lo = sGR[im][t - 1], hi = sGR[im][t + 1];
-        int gl = g[im], gr = g[im], rl = r[im], rr = r[im];
-        if (x > 0) { gl = (g[im] + (lo & 0xFF)) >> 1; rl = (r[im] + (lo >> 8)) >> 1; }
-        if (x < W - 1) { gr = (g[im] + (hi & 0xFF)) >> 1; rr = (r[im] + (hi >> 8)) >> 1; }
-        const int g0 = min(min(gl, gr), g[im]), g1 = max(max(gl, gr), g[im]);
-        const int q0 = min(min(rl, rr), r[im]), q1 = max(max(rl, rr), r[im]);
-        out[2 * im] = (uint32_t)g[im] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16);
-        out[2 * im + 1] = (uint32_t)r[im] | ((uint32_t)q0 << 8) | ((uint32_t)q1 << 16);
+        for (int im = 0; im < 2; im++) {
+            // ---- record of row y-1 from its own and its neighbours' (grad, raw) ----
+            const int g = gp[im], r = rp[im];
+            const int lo = sGR[par][im][tl], hi = sGR[par][im][tr];
+            int gl = g, gr = g, rl = r, rr = r;
+            if (x > 0) { gl = (g + (lo & 0xFF)) >> 1; rl = (r + (lo >> 8)) >> 1; }
+            if (x < W - 1) { gr = (g + (hi & 0xFF)) >> 1; rr = (r + (hi >> 8)) >> 1; }
+            const int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
+            const int q0 = min(min(rl, rr), r), q1 = max(max(rl, rr), r);
+            out[2 * im] = (uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16);
+            out[2 * im + 1] = (uint32_t)r | ((uint32_t)q0 << 8) | ((uint32_t)q1 << 16);
+            // ---- gradient of row y: 2*dh(y) + dh(y-1) + dh(y+1), rows replicated at the image border ----
+            const int de = (int)sI[par][im][tr] - (int)sI[par][im][tl];
+            const int dup = y > 0 ? dm[im] : d0[im];                        // row y-1 clamps to row 0
+            const int ddn = y < H - 1 ? de : d0[im];                        // row y+1 clamps to row H-1
+            gp[im] = xin ? min(max(2 * d0[im] + dup + ddn, -ft), ft) + ft : ft;
+            rp[im] = xin ? r0[im] : ft;
+            dm[im] = d0[im]; d0[im] = de; r0[im] = (ve >> (8 * im)) & 0xFF;
+        }
+        if (y > ya && t >= 2 && t <= 253 && x < W)
+            rec[((size_t)f * H + (y - 1)) * W + x] = make_uint4(out[0], out[1], out[2], out[3]);
     }
-    rec[((size_t)f * H + y) * W + x] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -860,7 +887,7 @@ __device__ __forceinline__ int lr_checked(const int16_t* __restrict__ dispw, con
 }
 
 #define LRM_TX 64
-#define LRM_TY 4
+#define LRM_TY 16     // 4 outputs per thread: a quarter of the workgroups of a 64 x 4 tile and 1.16x (not 1.55x) halo work
 __global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
                                                         int W, int H, int d12, int16_t* __restrict__ out)
 {
@@ -874,17 +901,21 @@ __global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restric
         sT[ty][tx] = (short)lr_checked(dispw, d2key, fo + (size_t)y * W, x, W, d12);
     }
     __syncthreads();
-    const int tx = t & (LRM_TX - 1), ty = t >> 6;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= W || y >= H) return;
-    int p0 = sT[ty][tx], p1 = sT[ty][tx + 1], p2 = sT[ty][tx + 2], p3 = sT[ty + 1][tx], p4 = sT[ty + 1][tx + 1],
-        p5 = sT[ty + 1][tx + 2], p6 = sT[ty + 2][tx], p7 = sT[ty + 2][tx + 1], p8 = sT[ty + 2][tx + 2];
-    V3D_SORT2(p1, p2); V3D_SORT2(p4, p5); V3D_SORT2(p7, p8); V3D_SORT2(p0, p1);
-    V3D_SORT2(p3, p4); V3D_SORT2(p6, p7); V3D_SORT2(p1, p2); V3D_SORT2(p4, p5);
-    V3D_SORT2(p7, p8); V3D_SORT2(p0, p3); V3D_SORT2(p5, p8); V3D_SORT2(p4, p7);
-    V3D_SORT2(p3, p6); V3D_SORT2(p1, p4); V3D_SORT2(p2, p5); V3D_SORT2(p4, p7);
-    V3D_SORT2(p4, p2); V3D_SORT2(p6, p4); V3D_SORT2(p4, p2);
-    out[fo + (size_t)y * W + x] = (int16_t)p4;
+    const int tx = t & (LRM_TX - 1), x = x0 + tx;
+    if (x >= W) return;
+#pragma unroll
+    for (int ty = t >> 6; ty < LRM_TY; ty += 4) {
+        const int y = y0 + ty;
+        if (y >= H) break;
+        int p0 = sT[ty][tx], p1 = sT[ty][tx + 1], p2 = sT[ty][tx + 2], p3 = sT[ty + 1][tx], p4 = sT[ty + 1][tx + 1],
+            p5 = sT[ty + 1][tx + 2], p6 = sT[ty + 2][tx], p7 = sT[ty + 2][tx + 1], p8 = sT[ty + 2][tx + 2];
+        V3D_SORT2(p1, p2); V3D_SORT2(p4, p5); V3D_SORT2(p7, p8); V3D_SORT2(p0, p1);
+        V3D_SORT2(p3, p4); V3D_SORT2(p6, p7); V3D_SORT2(p1, p2); V3D_SORT2(p4, p5);
+        V3D_SORT2(p7, p8); V3D_SORT2(p0, p3); V3D_SORT2(p5, p8); V3D_SORT2(p4, p7);
+        V3D_SORT2(p3, p6); V3D_SORT2(p1, p4); V3D_SORT2(p2, p5); V3D_SORT2(p4, p7);
+        V3D_SORT2(p4, p2); V3D_SORT2(p6, p4); V3D_SORT2(p4, p2);
+        out[fo + (size_t)y * W + x] = (int16_t)p4;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1224,7 +1255,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     const int px = W * H;
 
     prof_mark(h, ST_PREFILTER, st);
-    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 254), H, n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec);
+    hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 252), v3d_cdiv(H, PF_BAND), n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec);
     prof_mark(h, ST_COST, st);
     constexpr int COST_OUT = CostGeo<V3D_COST_LPC>::OUT;
     hipLaunchKernelGGL((k_cost<V3D_COST_LPC>), dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, h->cost_band), n), dim3(512), 0, st, h->rec, W, H, W1, h->cost_band, h->P2, h->C);
