@@ -36,62 +36,73 @@ __device__ __forceinline__ int gray_of(int b, int g, int r) { return (r * 9798 +
 // (128 + 8 BGR pixels when unsqueezing, 256 otherwise) is staged through LDS with coalesced dword loads:
 // per-tap byte loads at a 3-byte stride straight from HBM ran at 0.3 TB/s.
 // GRAY: write luma only; else write the BGR triple.
+#define SBS_ROWS 8    // rows per workgroup: the per-row work is tiny, one workgroup per row was bound by dispatch
 template <bool GRAY>
 __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ sbs, int W, int H, int pitch, int unsqueeze,
                                                    LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR,
                                                    size_t in_stride)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t sRow[(256 + 8) * 3 + 16];
+    __shared__ __attribute__((aligned(4))) uint8_t sRow[2][(256 + 8) * 3 + 16];
     const int hw = W >> 1, ow = unsqueeze ? W : hw;
     const int t = threadIdx.x;
-    const int xb = blockIdx.x * 256, x = xb + t, y = blockIdx.y, eye = blockIdx.z & 1, f = blockIdx.z >> 1;
+    const int xb = blockIdx.x * 256, x = xb + t, eye = blockIdx.z & 1, f = blockIdx.z >> 1;
+    const int ya = blockIdx.y * SBS_ROWS, yb = min(ya + SBS_ROWS, H);
     sbs += (size_t)f * in_stride;
     const size_t ostride = (size_t)ow * H * (GRAY ? 1 : 3);
     outL += f * ostride; outR += f * ostride;
-    const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;     // this eye's half row: hw BGR pixels
+    uint8_t* out = eye ? outR : outL;
 
     // source pixels [s0, s0 + ns) of the half row are needed by this block
     const int s0 = unsqueeze ? (xb >> 1) - 4 : xb;
     const int ns = unsqueeze ? 128 + 8 : 256;
-    int soff = 0;                                               // byte offset of pixel s0 inside sRow
-    if (s0 >= 0 && (s0 + ns < hw || (eye == 0 && s0 + ns <= hw))) {
-        // interior block: aligned dword loads of the span; the <= 3 bytes of over-read stay inside this image row
-        // (edge blocks take the clamped byte path)
-        const uintptr_t a = reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3);
-        const uint32_t* a0 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-        soff = (int)(a & 3);
-        const int nd = (soff + ns * 3 + 3) >> 2;
-        for (int i = t; i < nd; i += 256) reinterpret_cast<uint32_t*>(sRow)[i] = a0[i];
-    } else {
-        for (int i = t; i < ns * 3; i += 256) {
-            const int px = i / 3, c = i - px * 3;
-            sRow[i] = row[min(max(s0 + px, 0), hw - 1) * 3 + c];            // replicate border
-        }
-    }
-    __syncthreads();
-    if (x >= ow) return;
-    int b, g, r;
-    if (unsqueeze) {
-        // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x: sx = x/2 - 1, frac 0.75; odd x: sx = (x-1)/2, frac 0.25
-        const int odd = x & 1, sx = odd ? (x >> 1) : (x >> 1) - 1;
-        int ab = 0, ag = 0, ar = 0;
+    const bool interior = s0 >= 0 && (s0 + ns < hw || (eye == 0 && s0 + ns <= hw));
+    // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x: sx = x/2 - 1, frac 0.75; odd x: sx = (x-1)/2, frac 0.25
+    const int odd = x & 1, sx = odd ? (x >> 1) : (x >> 1) - 1;
+    int tp[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint8_t* p = sRow + soff + (sx + k - 3 - s0) * 3;
-            const int tp = taps.t[odd][k];
-            ab += p[0] * tp; ag += p[1] * tp; ar += p[2] * tp;
+    for (int k = 0; k < 8; k++) tp[k] = taps.t[odd][k];
+
+    for (int y = ya; y < yb; y++) {
+        uint8_t* sR = sRow[y & 1];                                  // double-buffered: one barrier per row
+        const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;     // this eye's half row: hw BGR pixels
+        int soff = 0;                                               // byte offset of pixel s0 inside sR
+        if (interior) {
+            // aligned dword loads of the span; the <= 3 bytes of over-read stay inside this image row
+            // (edge blocks take the clamped byte path)
+            const uintptr_t a = reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3);
+            const uint32_t* a0 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+            soff = (int)(a & 3);
+            const int nd = (soff + ns * 3 + 3) >> 2;
+            for (int i = t; i < nd; i += 256) reinterpret_cast<uint32_t*>(sR)[i] = a0[i];
+        } else {
+            for (int i = t; i < ns * 3; i += 256) {
+                const int px = i / 3, c = i - px * 3;
+                sR[i] = row[min(max(s0 + px, 0), hw - 1) * 3 + c];              // replicate border
+            }
         }
-        // vertical pass is the identity tap (2048); final descale by 2^22 with rounding, saturate to u8
-        b = min(max((int)(((long long)ab * 2048 + (1 << 21)) >> 22), 0), 255);
-        g = min(max((int)(((long long)ag * 2048 + (1 << 21)) >> 22), 0), 255);
-        r = min(max((int)(((long long)ar * 2048 + (1 << 21)) >> 22), 0), 255);
-    } else {
-        const uint8_t* p = sRow + soff + t * 3;
-        b = p[0]; g = p[1]; r = p[2];
+        __syncthreads();
+        if (x >= ow) continue;
+        int b, g, r;
+        if (unsqueeze) {
+            int ab = 0, ag = 0, ar = 0;
+            const uint8_t* p0 = sR + soff + (sx - 3 - s0) * 3;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint8_t* p = p0 + k * 3;
+                ab += p[0] * tp[k]; ag += p[1] * tp[k]; ar += p[2] * tp[k];
+            }
+            // vertical pass is the identity tap (2048): (a * 2048 + 2^21) >> 22 == (a + 2^10) >> 11 exactly (floor
+            // of the same rational), so the descale stays in 32 bits; saturate to u8
+            b = min(max((ab + 1024) >> 11, 0), 255);
+            g = min(max((ag + 1024) >> 11, 0), 255);
+            r = min(max((ar + 1024) >> 11, 0), 255);
+        } else {
+            const uint8_t* p = sR + soff + t * 3;
+            b = p[0]; g = p[1]; r = p[2];
+        }
+        if (GRAY) out[(size_t)y * ow + x] = (uint8_t)gray_of(b, g, r);
+        else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
     }
-    uint8_t* out = eye ? outR : outL;
-    if (GRAY) out[(size_t)y * ow + x] = (uint8_t)gray_of(b, g, r);
-    else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
 }
 
 static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsqueeze, uint8_t* L, uint8_t* R, bool gray, int n, size_t in_stride, hipStream_t st)
@@ -104,8 +115,8 @@ static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsquee
     lanczos4_taps_host(0.75f, taps.t[0]);
     lanczos4_taps_host(0.25f, taps.t[1]);
     const int ow = unsqueeze ? W : W / 2;
-    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), H, 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
-    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), H, 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
+    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
+    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }

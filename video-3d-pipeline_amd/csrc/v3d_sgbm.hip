@@ -1007,9 +1007,15 @@ __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ im
     }
 }
 
+// Two launches: LEVEL 0 joins the row pairs inside bands of VM_BAND rows (trees at most VM_BAND deep), LEVEL 1 the
+// band boundaries.  The partition is the same in any order; what changes is the depth of the parent chains the
+// racing unions build, i.e. how many dependent global loads a find costs.
+#define VM_BAND 16
+template <int LEVEL>
 __global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = LEVEL == 0 ? blockIdx.y + blockIdx.y / (VM_BAND - 1) : blockIdx.y * VM_BAND + VM_BAND - 1;
     if (x >= W || y + 1 >= H) return;
     const size_t fo = (size_t)blockIdx.z * W * H;
     const int16_t* im = img + fo; int* L = lab + fo;
@@ -1054,7 +1060,9 @@ static int launch_speckles(int16_t* img, int W, int H, int frames, int newVal, i
     const int px = W * H;
     int* lab = ws; int* rlen = ws + (size_t)px * frames; int* csz = ws + (size_t)px * frames * 2;
     hipLaunchKernelGGL(k_ccl_runs, dim3(H, 1, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab, rlen, csz);
-    hipLaunchKernelGGL(k_ccl_vmerge, dim3(v3d_cdiv(W, 256), H, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
+    // rows y with (y % VM_BAND) != VM_BAND-1 first (blockIdx.y enumerates them), then the band boundaries
+    hipLaunchKernelGGL(k_ccl_vmerge<0>, dim3(v3d_cdiv(W, 256), H - H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
+    if (H / VM_BAND > 0) hipLaunchKernelGGL(k_ccl_vmerge<1>, dim3(v3d_cdiv(W, 256), H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
     hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, px, maxSize, lab, rlen, csz);
     hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, img, px, newVal, maxSize, lab, csz);
     V3D_LAUNCH_CHECK();
