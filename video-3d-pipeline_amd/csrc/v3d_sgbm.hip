@@ -11,6 +11,7 @@
 //   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
 #include "v3d_common.h"
 #include <vector>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
@@ -741,6 +742,11 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     for (int j = 0; j < PF; j++) { cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(j))); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
     __syncthreads();
 
+    // The row loop exists twice: waves that own a strip-edge pixel (wave 0 / wave 15 of an inner strip) carry the
+    // poll and publish code, the other 14 run a copy without it -- no merge copies of the polled registers, no
+    // branch tests.  Every wave still executes one barrier per row.
+    auto rows = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
     for (int y0 = 0; y0 < H; y0 += PF) {
 #pragma unroll
         for (int j = 0; j < PF; j++) {
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 vec_unpack<NP>(sL1[prev][px][dl], p1);             // column x-1 (slot px holds pixel px-1)
                 vec_unpack<NP>(sL3[prev][px + 2][dl], p3);         // column x+1
                 uint32_t d1 = sDl[prev][px].x, d3 = sDl[prev][px + 2].y;
-                if (y > 0) {
+                if constexpr (EDGE) if (y > 0) {
                     const uint32_t tag = (a.seq << 12) | (uint32_t)y;          // row y-1 carries tag (y-1)+1
                     const int slot = (y - 1) & (VDD_RING - 1);
                     if (edge_l) if (lane_l) {                       // my pixel 0: column x0 - 1 lives in the left strip
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                     nd1 = nd3 = P2pk;
                 }
                 // ---- 3. publish row y as early as possible: granules for the neighbours, LDS for the strip ----
-                if (y + 1 < H) {
+                if constexpr (EDGE) if (y + 1 < H) {
                     const uint32_t tag = (a.seq << 12) | (uint32_t)(y + 1);
                     const int slot = y & (VDD_RING - 1);
                     if (edge_r) if (lane_r) {                       // my last column's L1 goes right
@@ -818,6 +824,8 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
             }
         }
     }
+    };
+    if (edge_l || edge_r) rows(std::true_type{}); else rows(std::false_type{});
     if (failed) atomicAdd(a.err, 1);
 }
 
