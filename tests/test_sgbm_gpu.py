@@ -46,6 +46,23 @@ def test_full_compute_bit_exact(native, oracle, matcher, W, H):
     assert (got[:, :64] == -16).all()
 
 
+# sizes that sit on the kernels' tile edges: k_cost strips of 60 cost columns x 90-row bands, k_prefilter 252 columns x
+# 64-row bands, lrcheck/median 64 x 16 tiles, the speckle filter's 16-row merge bands, k_vdd/k_hfused row groups
+EDGE_SIZES = [(64 + 120, 91), (64 + 61, 65), (253, 33), (505, 17), (64 + 59, 181), (317, 129)]
+
+
+@pytest.mark.parametrize("W,H", EDGE_SIZES)
+def test_tile_edge_sizes_bit_exact(native, oracle, W, H):
+    L, R = textured_pair(W, H, seed=11 * W + H)
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=2)
+    want = oracle.sgbm_compute(L, R)
+    got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    cv = m.debug_cost_volume(_dev(native, L), _dev(native, R)).cpu().numpy()
+    m.close()
+    assert np.array_equal(cv, oracle.cost_volume(L, R))
+    assert not mismatch_report(got, want, "disp16"), mismatch_report(got, want, "disp16")
+
+
 def test_mode_hh_8_paths(native, oracle):
     W, H = 240, 100
     L, R = textured_pair(W, H, seed=5)
