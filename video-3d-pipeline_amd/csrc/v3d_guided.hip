@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
 // thread version spent 72 % of its time in the LDS pipe).  One barrier per two rows, every input element is read
 // once per band (+ 2r warm-up rows), a/b/out leave as 16/16/8-byte stores.
 // ------------------------------------------------------------------------------------------------
+#ifndef GF_CH
+#define GF_CH 3      // 16-byte LDS reads in flight per plane in the horizontal phase
+#endif
 typedef double v3d_f64x2 __attribute__((ext_vector_type(2)));
 typedef float v3d_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -190,7 +193,6 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
     const int hgx = blockIdx.x * NOUT - RR + 2 * hq;
     const bool pair_in = 2 * hq >= RR && 2 * hq < 256 - RR;
     const bool px0 = pair_in && hgx < W, px1 = pair_in && hgx + 1 < W;
-    const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
     const bool vec_ok = px1 && (W & 1) == 0;                        // both pixels in the image and rows pair-aligned
 
     // bilinear source coordinates are separable: the x part is a per-thread constant, the y part per row
@@ -247,14 +249,17 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                             gn = cur[rr].g;
                             const int e = ya - RR + tA + rr;
                             const double fy = (e + 0.5) * sy - 0.5, wy = fy - floor(fy);
-                            const double top = (double)cur[rr].a0 * (1.0 - bwx) + (double)cur[rr].a1 * bwx;
-                            const double bot = (double)cur[rr].b0 * (1.0 - bwx) + (double)cur[rr].b1 * bwx;
-                            pn = top * (1.0 - wy) + bot * wy;
+                            // lerps as a + w * (b - a): one subtract and one fma each (the sweep is VALU-bound; the
+                            // last-ulp difference to the (1-w)*a + w*b form is 1e-13 of the 1e-3 bar)
+                            const double a0 = (double)cur[rr].a0, b0 = (double)cur[rr].b0;
+                            const double top = fma(bwx, (double)cur[rr].a1 - a0, a0);
+                            const double bot = fma(bwx, (double)cur[rr].b1 - b0, b0);
+                            pn = fma(wy, bot - top, top);
                         }
                         const int go = rg[j]; const double po = r1[j];   // row e - R leaves (zeros during warm-up)
                         rg[j] = gn; r1[j] = pn;
                         vg += gn - go; vgg += gn * gn - go * go;
-                        v0 += pn - po; v1 += (double)gn * pn - (double)go * po;
+                        v0 += pn - po; v1 = fma((double)gn, pn, fma(-(double)go, po, v1));
                     } else {
                         const double n0 = cur[rr].in ? cur[rr].n0 : 0.0, n1 = cur[rr].in ? cur[rr].n1 : 0.0;
                         const double o0 = r0[j], o1 = r1[j];
@@ -278,12 +283,12 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                             const v3d_f64x2* d = reinterpret_cast<const v3d_f64x2*>(&sVd[buf][hrow][q][0]) + (hq - RR / 2);
                             double f = 0.0, l = 0.0, c = 0.0;
 #pragma unroll
-                            for (int ch = 0; ch <= RR; ch += 3) {
-                                v3d_f64x2 w[3];
+                            for (int ch = 0; ch <= RR; ch += GF_CH) {
+                                v3d_f64x2 w[GF_CH];
 #pragma unroll
-                                for (int i = 0; i < 3; i++) if (ch + i <= RR) w[i] = d[ch + i];
+                                for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) w[i] = d[ch + i];
 #pragma unroll
-                                for (int i = 0; i < 3; i++) if (ch + i <= RR) {
+                                for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) {
                                     if (ch + i == 0) { f = w[i].x; c = w[i].y; }
                                     else if (ch + i == RR) { c += w[i].x; l = w[i].y; }
                                     else { c += w[i].x; c += w[i].y; }
@@ -311,6 +316,8 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                         }
                         const double s0a = cq[0] + fq[0], s0b = cq[0] + lq[0], s1a = cq[1] + fq[1], s1b = cq[1] + lq[1];
                         const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                        // (window widths recomputed here: two thread constants fewer keep sweep 1 inside 128 VGPRs)
+                        const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
                         const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
                         const size_t o = (size_t)y * W + hgx;
                         if (SWEEP == 1) {
@@ -321,9 +328,9 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
                                 const double inv = n ? invb : inva;
                                 const double mI = (double)(n ? sgb : sga) * (inv * (1.0 / 255.0)), mp = (n ? s0b : s0a) * inv;
                                 const double mII = (double)(n ? sggb : sgga) * (inv * (1.0 / 65025.0)), mIp = (n ? s1b : s1a) * (inv * (1.0 / 255.0));
-                                const double var = mII - mI * mI, cov = mIp - mI * mp;
+                                const double var = fma(-mI, mI, mII), cov = fma(-mI, mp, mIp);
                                 const double a = cov * gf_rcp(var + eps);
-                                ab[n][0] = a; ab[n][1] = mp - a * mI;
+                                ab[n][0] = a; ab[n][1] = fma(-a, mI, mp);
                             }
                             if (vec_ok) {
                                 v3d_f64x2 va = { ab[0][0], ab[1][0] }, vb = { ab[0][1], ab[1][1] };
