@@ -37,6 +37,9 @@ __device__ __forceinline__ int gray_of(int b, int g, int r) { return (r * 9798 +
 // per-tap byte loads at a 3-byte stride straight from HBM ran at 0.3 TB/s.
 // GRAY: write luma only; else write the BGR triple.
 #define SBS_ROWS 8    // rows per workgroup: the per-row work is tiny, one workgroup per row was bound by dispatch
+// Unsqueezing, a thread computes the output PAIR (2m, 2m+1): the two 8-tap windows (source pixels m-4..m+3 with the
+// frac-0.75 taps, m-3..m+4 with the frac-0.25 taps) overlap in 7 of 8 pixels, so 27 LDS bytes serve both instead of
+// 48; a block covers 512 output pixels of one eye row.  Without unsqueeze a thread copies one pixel (256 per block).
 template <bool GRAY>
 __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ sbs, int W, int H, int pitch, int unsqueeze,
                                                    LanczosTaps taps, uint8_t* __restrict__ outL, uint8_t* __restrict__ outR,
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
     __shared__ __attribute__((aligned(4))) uint8_t sRow[2][(256 + 8) * 3 + 16];
     const int hw = W >> 1, ow = unsqueeze ? W : hw;
     const int t = threadIdx.x;
-    const int xb = blockIdx.x * 256, x = xb + t, eye = blockIdx.z & 1, f = blockIdx.z >> 1;
+    const int xb = blockIdx.x * (unsqueeze ? 512 : 256), eye = blockIdx.z & 1, f = blockIdx.z >> 1;
     const int ya = blockIdx.y * SBS_ROWS, yb = min(ya + SBS_ROWS, H);
     sbs += (size_t)f * in_stride;
     const size_t ostride = (size_t)ow * H * (GRAY ? 1 : 3);
@@ -54,13 +57,11 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
 
     // source pixels [s0, s0 + ns) of the half row are needed by this block
     const int s0 = unsqueeze ? (xb >> 1) - 4 : xb;
-    const int ns = unsqueeze ? 128 + 8 : 256;
+    const int ns = unsqueeze ? 256 + 8 : 256;
     const bool interior = s0 >= 0 && (s0 + ns < hw || (eye == 0 && s0 + ns <= hw));
-    // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x: sx = x/2 - 1, frac 0.75; odd x: sx = (x-1)/2, frac 0.25
-    const int odd = x & 1, sx = odd ? (x >> 1) : (x >> 1) - 1;
-    int tp[8];
+    int tp0[8], tp1[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) tp[k] = taps.t[odd][k];
+    for (int k = 0; k < 8; k++) { tp0[k] = taps.t[0][k]; tp1[k] = taps.t[1][k]; }
 
     for (int y = ya; y < yb; y++) {
         uint8_t* sR = sRow[y & 1];                                  // double-buffered: one barrier per row
@@ -81,27 +82,37 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
             }
         }
         __syncthreads();
-        if (x >= ow) continue;
-        int b, g, r;
         if (unsqueeze) {
-            int ab = 0, ag = 0, ar = 0;
-            const uint8_t* p0 = sR + soff + (sx - 3 - s0) * 3;
+            // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x = 2m: sx = m - 1, frac 0.75; odd x = 2m + 1: sx = m, frac 0.25
+            const int x = xb + 2 * t;                               // even member of the pair; m = x / 2 = s0 + 4 + t
+            if (x >= ow) continue;
+            const uint8_t* p0 = sR + soff + t * 3;                  // pixel m - 4
+            int acc[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint8_t* p = p0 + k * 3;
-                ab += p[0] * tp[k]; ag += p[1] * tp[k]; ar += p[2] * tp[k];
+            for (int k = 0; k < 9; k++) {
+                const int b = p0[3 * k], g = p0[3 * k + 1], r = p0[3 * k + 2];
+                if (k < 8) { acc[0][0] += b * tp0[k]; acc[0][1] += g * tp0[k]; acc[0][2] += r * tp0[k]; }
+                if (k > 0) { acc[1][0] += b * tp1[k - 1]; acc[1][1] += g * tp1[k - 1]; acc[1][2] += r * tp1[k - 1]; }
             }
-            // vertical pass is the identity tap (2048): (a * 2048 + 2^21) >> 22 == (a + 2^10) >> 11 exactly (floor
-            // of the same rational), so the descale stays in 32 bits; saturate to u8
-            b = min(max((ab + 1024) >> 11, 0), 255);
-            g = min(max((ag + 1024) >> 11, 0), 255);
-            r = min(max((ar + 1024) >> 11, 0), 255);
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                if (x + n >= ow) break;
+                // vertical pass is the identity tap (2048): (a * 2048 + 2^21) >> 22 == (a + 2^10) >> 11 exactly (floor
+                // of the same rational), so the descale stays in 32 bits; saturate to u8
+                const int b = min(max((acc[n][0] + 1024) >> 11, 0), 255);
+                const int g = min(max((acc[n][1] + 1024) >> 11, 0), 255);
+                const int r = min(max((acc[n][2] + 1024) >> 11, 0), 255);
+                if (GRAY) out[(size_t)y * ow + x + n] = (uint8_t)gray_of(b, g, r);
+                else { uint8_t* o = out + ((size_t)y * ow + x + n) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
+            }
         } else {
+            const int x = xb + t;
+            if (x >= ow) continue;
             const uint8_t* p = sR + soff + t * 3;
-            b = p[0]; g = p[1]; r = p[2];
+            const int b = p[0], g = p[1], r = p[2];
+            if (GRAY) out[(size_t)y * ow + x] = (uint8_t)gray_of(b, g, r);
+            else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
         }
-        if (GRAY) out[(size_t)y * ow + x] = (uint8_t)gray_of(b, g, r);
-        else { uint8_t* o = out + ((size_t)y * ow + x) * 3; o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r; }
     }
 }
 
@@ -115,8 +126,8 @@ static int split_common(const uint8_t* sbs, int W, int H, int pitch, int unsquee
     lanczos4_taps_host(0.75f, taps.t[0]);
     lanczos4_taps_host(0.25f, taps.t[1]);
     const int ow = unsqueeze ? W : W / 2;
-    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
-    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
+    if (gray) hipLaunchKernelGGL(k_split_sbs<true>, dim3(v3d_cdiv(ow, unsqueeze ? 512 : 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
+    else hipLaunchKernelGGL(k_split_sbs<false>, dim3(v3d_cdiv(ow, unsqueeze ? 512 : 256), v3d_cdiv(H, SBS_ROWS), 2 * n), dim3(256), 0, st, sbs, W, H, pitch, unsqueeze, taps, L, R, in_stride);
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
