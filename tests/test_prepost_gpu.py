@@ -8,7 +8,7 @@ from conftest import mismatch_report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("W,H", [(64, 8), (322, 45), (960, 540), (1920, 1080)])
+@pytest.mark.parametrize("W,H", [(64, 8), (322, 45), (1030, 9), (2050, 3), (960, 540), (1920, 1080)])
 @pytest.mark.parametrize("unsqueeze", [True, False])
 def test_sbs_to_gray_bit_exact(native, oracle, W, H, unsqueeze):
     rng = np.random.default_rng(W * 3 + H)
