@@ -218,6 +218,12 @@ def test_upscaler_flow_with_manifest(tmp_path):
         up.process_depth_upscaling(str(ddir), str(tmp_path / "missing.mp4"))
     q1 = up.upscale_frame(lows[0].astype(np.float32), guides[0])
     assert q1.shape == (40, 64) and q1.dtype == np.float32
+    # alignment offset: depth_000000 guided by 4K frame 1
+    out2 = up.process_depth_upscaling(str(ddir), str(v4k), output_path=str(tmp_path / "shifted.mp4"), guide_start_frame=1)
+    man2 = json.loads(open(out2).read())
+    q0 = read_png16(os.path.join(man2["frames_dir"], "depth4k_000000.png"))
+    want0 = O.guided_upscale(lows[0].astype(np.float32), O.bgr_to_gray(guides[1]), 8, 1e-3)
+    assert np.abs(q0.astype(np.float64) - np.clip(np.rint(want0), 0, 65535)).max() <= 1
 
 
 def test_upscale_cli_error_exit(tmp_path, capsys):

@@ -69,8 +69,11 @@ class SimpleDepthUpscaler:
         return self.backend.upscale(depth_lo, guide_4k, self.radius, self.eps).cpu().numpy()
 
     def upscale_depth_maps_ffmpeg(self, depth_dir: str, target_width: int, target_height: int,
-                                  output_path: str, fps: float = 23.976, video_4k_path: str = None):
-        """ Upscale the depth_%06d.png sequence to target_width x target_height (name kept from the reference) """
+                                  output_path: str, fps: float = 23.976, video_4k_path: str = None,
+                                  guide_start_frame: int = 0):
+        """ Upscale the depth_%06d.png sequence to target_width x target_height (name kept from the reference).
+        guide_start_frame: index of the 4K frame that belongs to depth_000000 -- the alignment offset that
+        run_pipeline.py:45-50 computes and then drops; round(offset_seconds * fps), clamped at 0. """
         from . import sharding
 
         print(f"Processing depth upscaling...")
@@ -86,7 +89,7 @@ class SimpleDepthUpscaler:
         rank, world = sharding.rank_world()
         frames_dir = Path(str(Path(output_path).with_suffix("")) + "_frames")
         frames_dir.mkdir(parents=True, exist_ok=True)
-        guides = iter_frames(video_4k_path, 0, len(depth_files)) if (video_4k_path and rank == 0) else None
+        guides = iter_frames(video_4k_path, max(int(guide_start_frame), 0), len(depth_files)) if (video_4k_path and rank == 0) else None
         n = len(depth_files)
         for base in range(0, n, world):
             # rank 0 decodes one round of guide frames and broadcasts it; rank r keeps frame base + r
@@ -128,7 +131,7 @@ class SimpleDepthUpscaler:
         return output_path
 
     def process_depth_upscaling(self, depth_dir: str, video_4k_path: str, output_path: str = None,
-                                force_reprocess: bool = False) -> str:
+                                force_reprocess: bool = False, guide_start_frame: int = 0) -> str:
         """ Main pipeline for depth upscaling """
         print(f"Processing depth upscaling...")
         print(f"Depth maps: {depth_dir}")
@@ -150,7 +153,8 @@ class SimpleDepthUpscaler:
             return str(output_path)
 
         result = self.upscale_depth_maps_ffmpeg(depth_dir=depth_dir, target_width=target_width, target_height=target_height,
-                                                output_path=str(output_path), fps=fps, video_4k_path=video_4k_path)
+                                                output_path=str(output_path), fps=fps, video_4k_path=video_4k_path,
+                                                guide_start_frame=guide_start_frame)
         print(f"✓ Depth upscaling complete!")
         print(f"  Input: {depth_dir}")
         print(f"  Output: {result}")
@@ -166,11 +170,14 @@ def main(argv=None):
     parser.add_argument('--output', help='Output path for 4K depth video')
     parser.add_argument('--no-nvenc', action='store_true', help='Disable NVENC, use CPU encoding')
     parser.add_argument('--force', action='store_true', help='Force reprocessing even if output exists')
+    parser.add_argument('--guide-start-frame', type=int, default=0,
+                        help='4K frame that matches depth_000000 (alignment offset in frames; default 0)')
     args = parser.parse_args(argv)
     try:
         upscaler = SimpleDepthUpscaler(use_nvenc=not args.no_nvenc)
         output_path = upscaler.process_depth_upscaling(depth_dir=args.depth_dir, video_4k_path=args.video_4k,
-                                                       output_path=args.output, force_reprocess=args.force)
+                                                       output_path=args.output, force_reprocess=args.force,
+                                                       guide_start_frame=args.guide_start_frame)
         print(f"\n✓ Success! 4K depth video: {output_path}")
         print(f"Ready for VisionDepth3D processing!")
     except Exception as e:
