@@ -205,21 +205,25 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
     // every VMEM instruction of the row loop is issued unconditionally (v3d_common.h: raw buffer access): threads
     // that stage nothing, halo columns and the warm-up rows are switched off through an out-of-range offset
     const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)H * W1 * (V3D_D * 2u));
-    const uint32_t ld_off = ld_any ? 0u : V3D_BUF_OOB;
+    const uint32_t la = ld_any ? ld_a * 4u : V3D_BUF_OOB, lb = ld_any ? ld_b * 4u : V3D_BUF_OOB;   // + row offset < 2^31: bit 31 survives
     auto fetch = [&](int k) -> uint2 {
         const uint32_t ro = (uint32_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 16u;
-        return make_uint2(buf_load_u32(rs_rec, (ro + ld_a * 4u) | ld_off), buf_load_u32(rs_rec, (ro + ld_b * 4u) | ld_off));
+        return make_uint2(buf_load_u32(rs_rec, ro + la), buf_load_u32(rs_rec, ro + lb));
     };
     if (ld_any) stage(0, fetch(0));
-    uint2 n1 = fetch(1), n2 = fetch(2);
+    // records in flight: nr[p] holds the row whose index has parity p; a slot is refilled (row + 2) right after the
+    // stage that consumed it, so both are statically indexed and each load has two row times to land
+    uint2 nr[2];
+    nr[1] = fetch(1); nr[0] = fetch(2);
     __syncthreads();
 
     uint32_t ring[5][NP], vs[NP];                               // last five rows' horizontal sums + their running sum
 #pragma unroll
-    for (int j = 0; j < NP; j++) { vs[j] = 0u;
+    for (int j = 0; j < NP; j++) { vs[j] = pk_bcast(P2);         // P2 rides in the running sum: C = P2 + box sum
 #pragma unroll
         for (int i = 0; i < 5; i++) ring[i][j] = 0u; }
-    const uint32_t P2pk = pk_bcast(P2);
+    // C store offsets: per-thread part (out-of-range marker for halo columns) + uniform row part
+    const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * V3D_D + EP * dq) * 2u : V3D_BUF_OOB;
 
     for (int k10 = 0; k10 < nrows; k10 += 10) {
 #pragma unroll
@@ -227,7 +231,6 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
         const int k = k10 + s10;                                // shifts, every LDS address is base + immediate
         if (k >= nrows) break;                                  // uniform
         const int slot = s10 % 5, buf = s10 & 1;
-        const uint2 n3 = fetch(k + 3);
 
         // ---- BT cost of (xrc, d = EP*dq .. +EP-1) on row clamp(ys - 2 + k): quantities g, g_lo, g_hi, r, r_lo, r_hi ----
         // the two planes (gradient, raw) one after the other, fenced: all 6 x NP right-image dwords in flight at once
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
         }
         sPix[buf][col][dq] = Packer<NP>::go(pix);
 
-        if (k + 1 < nrows && ld_any && !(V3D_COST_DBG & 4)) stage(buf ^ 1, n1);
-        n1 = n2; n2 = n3;
+        if (k + 1 < nrows && ld_any && !(V3D_COST_DBG & 4)) stage(buf ^ 1, nr[buf ^ 1]);     // row k+1 has parity buf^1 (k10 is even)
+        nr[buf ^ 1] = fetch(k + 3);
         __syncthreads();
 
         // ---- 5-tap horizontal sum on packed u16 pairs, 5-row vertical running sum ----
@@ -270,11 +273,8 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
             }
 #pragma unroll
             for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
-            uint32_t cv[NP];
-#pragma unroll
-            for (int j = 0; j < NP; j++) cv[j] = vs[j] + P2pk;
-            const uint32_t off = (uint32_t)(((ys + k - 4) * W1 + (xr0 - 2 + col)) * V3D_D + EP * dq) * 2u;
-            buf_store_stream(rs_c, (out_col && k >= 4) ? off : V3D_BUF_OOB, Packer<NP>::go(cv));
+            const uint32_t st_row = k >= 4 ? (uint32_t)((ys + k - 4) * W1) * (V3D_D * 2u) : V3D_BUF_OOB;     // uniform
+            buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(vs));   // saturating: marker + marker stays out of range
         }
       }
     }
