@@ -143,17 +143,17 @@ __device__ __forceinline__ void buf_store_stream(__amdgpu_buffer_rsrc_t r, uint3
 
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2).  Map the linear
 // workgroup id so that every XCD walks a CONTIGUOUS range of logical tiles: neighbouring tiles, which re-read each
-// other's halo, then share an L2.  Speed only -- nothing may depend on the placement.  Falls back to the identity
-// when the grid size is not a multiple of 8.
+// other's halo, then share an L2.  Speed only -- nothing may depend on the placement.
+__device__ __forceinline__ uint32_t xcd_linear(uint32_t lin, uint32_t nb)
+{
+    const uint32_t x = lin & 7u, q = nb >> 3, r = nb & 7u;       // XCD x owns q (+1 if x < r) consecutive logical tiles
+    return x * q + min(x, r) + (lin >> 3);
+}
 __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
 {
-    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
     const uint32_t nb = gridDim.x * gridDim.y * gridDim.z;
-    if ((nb & 7u) == 0u) {
-        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const uint32_t lg = (lin & 7u) * (nb >> 3) + (lin >> 3);
-        bx = (int)(lg % gridDim.x); by = (int)((lg / gridDim.x) % gridDim.y); bz = (int)(lg / (gridDim.x * gridDim.y));
-    }
+    const uint32_t lg = xcd_linear(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nb);
+    bx = (int)(lg % gridDim.x); by = (int)((lg / gridDim.x) % gridDim.y); bz = (int)(lg / (gridDim.x * gridDim.y));
 }
 
 #endif

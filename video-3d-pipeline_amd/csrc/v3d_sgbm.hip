@@ -137,7 +137,7 @@ template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const 
 // but the unbanded kernel it needs has too few waves to gain anything.)
 template <int LPC>
 __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
-                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C)
+                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C, int xcd_order)
 {
     typedef CostGeo<LPC> G;
     constexpr int EP = G::EP, NP = G::NP, COLS = G::COLS, OUT = G::OUT, NREC = G::NREC;
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
     const int tid = threadIdx.x, col = tid / LPC, dq = tid % LPC;
     // XCD-aware tile order (v3d_common.h): neighbouring strips re-read each other's halo records (128 staged columns
     // per 60 outputs); on one XCD those re-reads hit its L2 (k_cost FETCH_SIZE -64 %, 2.2 -> 2.0 ms per 30 frames)
-    int bxi, byi, bzi;
-    xcd_tile(bxi, byi, bzi);
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    if (xcd_order) xcd_tile(bxi, byi, bzi);
     const int xr0 = bxi * OUT;
     const int ys = byi * band_h, ye = min(ys + band_h, H);
     const int f = bzi;
@@ -658,6 +658,7 @@ struct VddArgs {
     uint32_t seq;
     unsigned long long* gran;           // [frame][strip][2 dirs][VDD_RING][VDD_GRAN]
     int* err;
+    int xcd;                            // 1: XCD-contiguous strip order.  Measured slower (3.48 -> 4.58 ms per 30 frames): off
 };
 
 // wait for N data granules (+ the delta granule if want_d) of one row: all loads of a poll round go out together
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave index as an SGPR: edge-wave branches stay scalar
     const int px = wv * PPW + lane / LPP, dl = lane % LPP;      // pixel inside the strip, disparity group
-    const int frame = blockIdx.x / a.nstrips, strip = blockIdx.x - frame * a.nstrips;
+    const int vb = a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int frame = vb / a.nstrips, strip = vb - frame * a.nstrips;
     const int W1 = a.W1, H = a.H;
     const int x = strip * PXS + px;
     const bool colok = x < W1;
@@ -1099,6 +1101,7 @@ struct v3d_sgbm {
     int vdd_mode;                               // 0 off, 1 on
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
     int cost_band;                              // rows per k_cost workgroup
+    int vdd_xcd, cost_xcd;
     int vdd_mf4, vdd_mf8;                       // co-residency bound (frames per launch) of each mapping
     bool hfused;
     int32_t* labels;
@@ -1202,6 +1205,8 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         h->vdd_mf8 = (b8 * ncu * 9 / 10) / v3d_cdiv(maxW - V3D_D, 128);
         if (h->vdd_mf4 < 1 || h->vdd_mf8 < 1) h->vdd_mode = 0;
     }
+    { const char* e7 = getenv("V3D_VDD_XCD"); h->vdd_xcd = e7 ? atoi(e7) : 0; }
+    { const char* e8 = getenv("V3D_COST_XCD"); h->cost_xcd = e8 ? atoi(e8) : 1; }
     { const char* e6 = getenv("V3D_COST_BAND"); h->cost_band = e6 && atoi(e6) >= 8 ? atoi(e6) : 90; }
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
@@ -1257,7 +1262,7 @@ static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t 
         v.C = h->C + (size_t)f0 * H * W1 * V3D_D; v.S = h->S + (size_t)f0 * H * W1 * V3D_D;
         v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
         v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
-        v.gran = h->gran; v.err = h->vdd_err;
+        v.gran = h->gran; v.err = h->vdd_err; v.xcd = h->vdd_xcd;
         const dim3 grid(v.nstrips * nf), block(1024);
         if (dpl == 8) { if (rev) hipLaunchKernelGGL((k_vdd<8, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<8, false>), grid, block, 0, st, v); }
         else { if (rev) hipLaunchKernelGGL((k_vdd<4, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<4, false>), grid, block, 0, st, v); }
@@ -1278,7 +1283,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     hipLaunchKernelGGL(k_prefilter, dim3(v3d_cdiv(W, 252), v3d_cdiv(H, PF_BAND), n), dim3(256), 0, st, left, right, W, H, pitch, frame_stride, h->ftzero, h->rec);
     prof_mark(h, ST_COST, st);
     constexpr int COST_OUT = CostGeo<V3D_COST_LPC>::OUT;
-    hipLaunchKernelGGL((k_cost<V3D_COST_LPC>), dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, h->cost_band), n), dim3(512), 0, st, h->rec, W, H, W1, h->cost_band, h->P2, h->C);
+    hipLaunchKernelGGL((k_cost<V3D_COST_LPC>), dim3(v3d_cdiv(W1, COST_OUT), v3d_cdiv(H, h->cost_band), n), dim3(512), 0, st, h->rec, W, H, W1, h->cost_band, h->P2, h->C, h->cost_xcd);
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_V2, st);
     if (last_stage == 1) return V3D_OK;
