@@ -301,6 +301,7 @@ struct ChainArgs {
     int uniq;                 // uniquenessRatio
     int16_t* dispw;           // MODE 2: [nframes][H][W]
     uint32_t* d2key;          // MODE 2: [nframes][H][W]
+    int xcd;                  // k_hfused: XCD-contiguous row-group order (V3D_HF_XCD=1).  Measured 4 % slower: off
 };
 
 // L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta ; returns delta' = min_d L[d] + P2 (both halves)
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int W1 = a.W1, H = a.H;
     const int groups = (H + PPW - 1) / PPW;
-    const int gw = blockIdx.x * 4 + wib;
+    const int gw = (a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x) * 4 + wib;
     const int frame = gw / groups, grp = gw - frame * groups;
     if (frame >= a.nframes) return;                            // wave-uniform; no block-wide barriers below
 
@@ -1101,7 +1102,7 @@ struct v3d_sgbm {
     int vdd_mode;                               // 0 off, 1 on
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
     int cost_band;                              // rows per k_cost workgroup
-    int vdd_xcd, cost_xcd;
+    int vdd_xcd, cost_xcd, hf_xcd;
     int vdd_mf4, vdd_mf8;                       // co-residency bound (frames per launch) of each mapping
     bool hfused;
     int32_t* labels;
@@ -1206,6 +1207,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         if (h->vdd_mf4 < 1 || h->vdd_mf8 < 1) h->vdd_mode = 0;
     }
     { const char* e7 = getenv("V3D_VDD_XCD"); h->vdd_xcd = e7 ? atoi(e7) : 0; }
+    { const char* e9 = getenv("V3D_HF_XCD"); h->hf_xcd = e9 ? atoi(e9) : 0; }
     { const char* e8 = getenv("V3D_COST_XCD"); h->cost_xcd = e8 ? atoi(e8) : 1; }
     { const char* e6 = getenv("V3D_COST_BAND"); h->cost_band = e6 && atoi(e6) >= 8 ? atoi(e6) : 90; }
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
@@ -1290,7 +1292,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
 
     ChainArgs a;
     a.C = h->C; a.S = h->S; a.W1 = W1; a.H = H; a.W = W; a.nframes = n; a.P1 = h->P1; a.P2 = h->P2; a.uniq = h->uniq;
-    a.dispw = h->dispw; a.d2key = h->d2key;
+    a.dispw = h->dispw; a.d2key = h->d2key; a.xcd = h->hf_xcd;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
     const bool use_vdd = h->vdd_mode && H < 4095;
