@@ -310,9 +310,16 @@ __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t
                                                uint32_t (&L)[NP], uint32_t P1pk, uint32_t P2pk, bool first_lane, bool last_lane)
 {
     const uint32_t MAXPK = 0x7FFF7FFFu;
-    uint32_t prev = dpp_mov<V3D_DPP_ROW_SHR(1)>(MAXPK, p[NP - 1]);
-    uint32_t next = dpp_mov<V3D_DPP_ROW_SHL(1)>(MAXPK, p[0]);
-    if (LPP < 16) { prev = first_lane ? MAXPK : prev; next = last_lane ? MAXPK : next; }
+    uint32_t prev, next;
+    if (LPP < 16) {
+        // several pixels per DPP row: the pixel-edge lanes are patched by a select anyway, so the shift needs no
+        // pre-initialised destination (saves the v_mov of the fill value per shift)
+        prev = dpp_xchg<V3D_DPP_ROW_SHR(1)>(p[NP - 1]); next = dpp_xchg<V3D_DPP_ROW_SHL(1)>(p[0]);
+        prev = first_lane ? MAXPK : prev; next = last_lane ? MAXPK : next;
+    } else {
+        prev = dpp_mov<V3D_DPP_ROW_SHR(1)>(MAXPK, p[NP - 1]);     // one pixel per DPP row: lanes without a source keep the fill
+        next = dpp_mov<V3D_DPP_ROW_SHL(1)>(MAXPK, p[0]);
+    }
     uint32_t m[NP + 1];
     m[0] = alignbit(p[0], prev, 16);
 #pragma unroll
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     const int W1 = a.W1, H = a.H;
     const int x = strip * PXS + px;
     const bool colok = x < W1;
+    const bool ragged = __builtin_amdgcn_readfirstlane((strip + 1) * PXS > W1);   // this strip sticks out of the image
     const int xc = min(x, W1 - 1);
     const size_t fbase = (size_t)frame * H * W1 * V3D_D;
     const int16_t* Cp = a.C + fbase + (size_t)xc * V3D_D + dl * DPL;
@@ -792,8 +800,8 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 uint32_t L1[NP], L2[NP], L3[NP];
                 uint32_t nd1 = chain_step<NP, LPP>(p1, d1, cv, L1, P1pk, P2pk, first_lane, last_lane);
                 uint32_t nd3 = chain_step<NP, LPP>(p3, d3, cv, L3, P1pk, P2pk, first_lane, last_lane);
-                if (!colok) {                                       // columns beyond the image: out-of-image state
-#pragma unroll
+                if (ragged) if (!colok) {                           // columns beyond the image (last strip only; `ragged`
+#pragma unroll                                                      //  is uniform, so full strips skip the block): out-of-image state
                     for (int i = 0; i < NP; i++) L1[i] = L3[i] = 0u;
                     nd1 = nd3 = P2pk;
                 }
