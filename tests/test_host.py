@@ -255,3 +255,34 @@ def test_config0_geometry_plumbing(tmp_path):
     a = read_png16(out / "depth_000000.png")
     assert a.shape == (540, 960) and a.max() == 65535 and a.min() == 0           # per-frame min-max normalisation
     assert np.array_equal(a, read_png16(out / "depth_000002.png"))                # identical input frame -> identical PNG
+
+
+def test_png16_encoder_roundtrip_and_pool(tmp_path):
+    """the zlib-based writer produces PNGs any reader decodes to the same samples (depth.py:406 / upscale.py:43 format);
+    the writer pool writes them all and reports a failed write at close()"""
+    from PIL import Image
+    from video_3d_pipeline.utils import encode_png16, read_png16, PngWriterPool
+    rng = np.random.default_rng(7)
+    cases = [rng.integers(0, 65536, (37, 53), dtype=np.uint16), np.full((1, 1), 65535, np.uint16),
+             np.zeros((5, 1), np.uint16), (np.arange(300 * 7) % 65536).astype(np.uint16).reshape(7, 300)]
+    for k, a in enumerate(cases):
+        pth = tmp_path / f"c{k}.png"
+        pth.write_bytes(encode_png16(a))
+        with Image.open(pth) as im:
+            assert im.mode in ("I;16", "I;16B", "I") and im.size == (a.shape[1], a.shape[0])
+            assert np.array_equal(np.asarray(im).astype(np.uint16), a)
+        assert np.array_equal(read_png16(pth), a)
+    with pytest.raises(ValueError):
+        encode_png16(np.zeros((2, 2, 3), np.uint16))
+    imgs = [rng.integers(0, 65536, (64, 80), dtype=np.uint16) for _ in range(40)]
+    with PngWriterPool(workers=4, max_pending=6) as pool:
+        for k, a in enumerate(imgs):
+            pool.submit(tmp_path / f"p{k:03d}.png", a)
+    for k, a in enumerate(imgs):
+        assert np.array_equal(read_png16(tmp_path / f"p{k:03d}.png"), a)
+    pool = PngWriterPool(workers=2)
+    pool.submit(tmp_path / "ok.png", imgs[0])
+    pool.submit(tmp_path / "no_such_dir" / "x.png", imgs[0])
+    with pytest.raises(OSError):
+        pool.close()
+    assert (tmp_path / "ok.png").exists()

@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .utils import create_work_directory, get_video_info, iter_frames, write_png16
+from .utils import PngWriterPool, create_work_directory, get_video_info, iter_frames, write_png16
 
 
 class HipStereoBackend:
@@ -288,6 +288,9 @@ class HybridStereoDepthExtractor:
         rank, world = sharding.rank_world()
         processed_count = 0
         batch, batch_idx = [], []
+        # PNG compression (zlib) costs ~20 ms per 1080p map on one core, the GPU path 0.5 ms: the maps of a batch go to
+        # a bounded pool of writer threads and compress while the next batch is decoded and computed
+        writers = PngWriterPool()
 
         def flush():
             nonlocal processed_count
@@ -295,22 +298,23 @@ class HybridStereoDepthExtractor:
                 return
             depth = self.backend.sbs_to_disparity(batch, self.unsqueeze_sbs)
             for j, frame_idx in enumerate(batch_idx):
-                write_png16(cache_path / f"depth_{frame_idx:06d}.png", self.backend.normalise_u16(depth[j]))
+                writers.submit(cache_path / f"depth_{frame_idx:06d}.png", self.backend.normalise_u16(depth[j]))
                 processed_count += 1
-            print(f"✓ Saved batch depth maps ({processed_count} on rank {rank})")
+            print(f"✓ Queued batch depth maps ({processed_count} on rank {rank})")
             batch.clear()
             batch_idx.clear()
 
         seen = 0
-        for i, frame in enumerate(iter_frames(video_path, start_frame, frame_count)):
-            seen += 1
-            if not sharding.owns(i, rank, world):          # frame i -> rank i mod world (round-robin)
-                continue
-            batch.append(frame)
-            batch_idx.append(i)
-            if len(batch) == self.batch_size:
-                flush()
-        flush()
+        with writers:
+            for i, frame in enumerate(iter_frames(video_path, start_frame, frame_count)):
+                seen += 1
+                if not sharding.owns(i, rank, world):          # frame i -> rank i mod world (round-robin)
+                    continue
+                batch.append(frame)
+                batch_idx.append(i)
+                if len(batch) == self.batch_size:
+                    flush()
+            flush()
         if seen == 0:
             raise ValueError("No frames extracted from video")
         sharding.barrier()
