@@ -252,3 +252,41 @@ def test_noise_and_flat_inputs(native, oracle, matcher):
     sat = np.where(rng.random((H, W)) < 0.5, 0, 255).astype(np.uint8)          # saturated gradients everywhere
     got = matcher.compute(_dev(native, sat), _dev(native, np.roll(sat, -11, axis=1))).cpu().numpy()
     assert not mismatch_report(got, oracle.sgbm_compute(sat, np.roll(sat, -11, axis=1)), "binary")
+
+
+def _fuzz_case(seed):
+    """random geometry, parameters and image content, all derived from the seed"""
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.integers(70, 420)); H = int(rng.integers(1, 150))
+    if seed % 7 == 0: H = int(rng.integers(1, 4))                 # one to three rows
+    if seed % 5 == 0: W = 69 + seed % 3                           # a handful of cost columns
+    kind = seed % 4
+    if kind == 0:
+        L, R = textured_pair(W, H, seed=seed)
+    elif kind == 1:                                               # unrelated noise: every check fails somewhere
+        L = rng.integers(0, 256, (H, W), dtype=np.uint8); R = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    elif kind == 2:                                               # hard edges and saturated patches
+        L = np.where(rng.random((H, W)) < 0.5, 0, 255).astype(np.uint8)
+        L = np.repeat(np.repeat(L[::4, ::4], 4, axis=0), 4, axis=1)[:H, :W] if H >= 4 and W >= 4 else L
+        R = np.roll(L, -int(rng.integers(0, 40)), axis=1)
+    else:                                                         # smooth ramps: long runs of equal costs (tie-breaks)
+        x = np.linspace(0, 255, W)[None, :] * np.ones((H, 1)); L = x.astype(np.uint8); R = np.roll(L, -7, axis=1)
+    P1 = int(rng.integers(1, 900)); P2 = int(rng.integers(P1 + 1, 6000))
+    kw = dict(P1=P1, P2=P2, uniquenessRatio=int(rng.integers(0, 60)), disp12MaxDiff=int(rng.integers(1, 8)),
+              speckleWindowSize=int(rng.choice([0, 20, 100, 300])), speckleRange=int(rng.integers(1, 40)),
+              preFilterCap=int(rng.choice([0, 15, 31])), mode=int(rng.integers(0, 2)))
+    return W, H, np.ascontiguousarray(L), np.ascontiguousarray(R), kw
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_fuzz_geometry_parameters_content(native, oracle, seed):
+    """seeded fuzz over sizes (down to one row / five cost columns), every accepted parameter and four kinds of image
+    content; final disparity bit-exact against the oracle, no lock-step time-outs"""
+    W, H, L, R, kw = _fuzz_case(seed)
+    want = oracle.sgbm_compute(L, R, oracle.default_params(**kw))
+    m = native.StereoSGBM(max_width=W, max_height=H, **kw)
+    got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    errs = m.sync_errors()
+    m.close()
+    assert errs == 0
+    assert not mismatch_report(got, want, f"seed {seed} {W}x{H} {kw}"), mismatch_report(got, want, f"seed {seed} {W}x{H} {kw}")
