@@ -68,7 +68,9 @@ def broadcast_guide_round(round_frames, shape, device, src=0):
     H, W = shape
     if world == 1 or not (dist.is_available() and dist.is_initialized()):
         f = round_frames[0] if round_frames else None
-        return None if f is None else torch.from_numpy(np.ascontiguousarray(f)).to(device)
+        if f is None or not isinstance(f, np.ndarray):          # already a device tensor (single-rank fast path)
+            return f
+        return torch.from_numpy(np.ascontiguousarray(f)).to(device)
     buf = torch.zeros((world, H, W), dtype=torch.uint8, device=device)
     valid = torch.zeros(world, dtype=torch.uint8, device=device)
     if rank == src:

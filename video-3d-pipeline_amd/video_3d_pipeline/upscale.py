@@ -18,7 +18,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .utils import PngWriterPool, get_video_info, iter_frames, read_png16
+from .utils import PngWriterPool, get_video_info, iter_frames, prefetch_map, read_png16
 
 GUIDED_RADIUS = 8       # at 4K; the reference specifies nothing
 GUIDED_EPS = 1e-3       # on [0,1]-scaled guide
@@ -47,7 +47,8 @@ class HipUpscaleBackend:
         """guided upscale, rounded and clamped to the 16-bit range of the PNG sink"""
         torch = self.torch
         q = self.upscale(depth_lo, guide, r, eps)
-        return torch.clamp(torch.round(q), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
+        # int32 -> int16 keeps the low 16 bits: the uint16 bit pattern leaves the device as 2 bytes per pixel
+        return torch.clamp(torch.round(q), 0, 65535).to(torch.int32).to(torch.int16).cpu().numpy().view(np.uint16)
 
     def flat_guide(self, h, w):
         return self.torch.full((h, w), 128, dtype=self.torch.uint8, device=self.device)
@@ -91,6 +92,8 @@ class SimpleDepthUpscaler:
         frames_dir.mkdir(parents=True, exist_ok=True)
         guides = iter_frames(video_4k_path, max(int(guide_start_frame), 0), len(depth_files)) if (video_4k_path and rank == 0) else None
         n = len(depth_files)
+        # this rank's depth maps, decoded a few files ahead on reader threads (PNG inflate is the slowest host step)
+        my_depth = prefetch_map(read_png16, [depth_files[i] for i in range(rank, n, world)])
         with PngWriterPool() as writers:                  # 4K 16-bit PNGs: ~80 ms of zlib each, compressed off the main thread
             for base in range(0, n, world):
                 # rank 0 decodes one round of guide frames and broadcasts it; rank r keeps frame base + r
@@ -99,13 +102,15 @@ class SimpleDepthUpscaler:
                     round_frames = []
                     for _ in range(world):
                         f = next(guides, None) if guides is not None else None
-                        round_frames.append(None if f is None else self.backend.to_luma(f).cpu().numpy())
+                        # one rank: the luma stays on the device; several: it travels as a host array into the round buffer
+                        luma = None if f is None else self.backend.to_luma(f)
+                        round_frames.append(luma if (luma is None or world == 1) else luma.cpu().numpy())
                 i = base + rank
                 guide = sharding.broadcast_guide_round(round_frames, (target_height, target_width), self.backend.device) \
                     if video_4k_path else None
                 if i >= n:
                     continue
-                d16 = read_png16(depth_files[i]).astype(np.float32)
+                d16 = next(my_depth).astype(np.float32)
                 if guide is None:     # no 4K frame for this index: guide with a flat image == plain smoothing upsample
                     guide = self.backend.flat_guide(target_height, target_width)
                 writers.submit(frames_dir / f"depth4k_{i:06d}.png", self.backend.upscale_u16(d16, guide, self.radius, self.eps))

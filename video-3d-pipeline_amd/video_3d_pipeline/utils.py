@@ -168,7 +168,7 @@ def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int]
 
 def encode_png16(img_u16: np.ndarray, level: int = 1) -> bytes:
     """16-bit single-channel PNG as bytes (what cv2.imwrite produces for a uint16 array, depth.py:406).
-    Written with zlib directly: filter type "up" per row, deflate level 1.  zlib.compress releases the GIL, so a pool
+    Written with zlib directly: filter type "sub" per row, deflate level 1.  zlib.compress releases the GIL, so a pool
     of writer threads scales with the host cores (Pillow's encoder holds it: 8 threads were no faster than one)."""
     import struct
     import zlib
@@ -178,11 +178,10 @@ def encode_png16(img_u16: np.ndarray, level: int = 1) -> bytes:
     h, w = a.shape
     be = a.astype(">u2").view(np.uint8).reshape(h, 2 * w)            # PNG samples are big-endian
     raw = np.empty((h, 1 + 2 * w), np.uint8)
-    raw[0, 0] = 0
-    raw[0, 1:] = be[0]
-    if h > 1:
-        raw[1:, 0] = 2                                               # filter "up": byte minus the byte above, mod 256
-        np.subtract(be[1:], be[:-1], out=raw[1:, 1:])
+    raw[:, 0] = 1                                                    # filter "sub" on every row: byte minus the byte one
+    raw[:, 1:3] = be[:, :2]                                          # pixel (2 bytes) to the left, mod 256 -- one array
+    if w > 1:                                                        # op to encode, ONE cumulative sum to decode
+        np.subtract(be[:, 2:], be[:, :-2], out=raw[:, 3:])
 
     def chunk(tag: bytes, body: bytes) -> bytes:
         return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
@@ -253,10 +252,90 @@ class PngWriterPool:
         return False
 
 
+def _decode_png16_fast(data: bytes):
+    """16-bit gray, non-interlaced PNG whose rows use only the filters none / sub / up (this package's own writer
+    uses "sub") decoded with zlib + NumPy, both of which release the GIL -- reader threads scale, Pillow's decoder holds
+    it.  Returns None for anything else (palette, 8-bit, interlaced, average / Paeth rows): the caller falls back."""
+    import struct
+    import zlib
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        return None
+    pos, idat, hdr = 8, [], None
+    while pos + 8 <= len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+        pos += 12 + n
+    if hdr is None or hdr[2:] != (16, 0, 0, 0, 0) or not idat:
+        return None
+    w, h = hdr[0], hdr[1]
+    try:
+        raw = np.frombuffer(zlib.decompress(b"".join(idat), 15, h * (1 + 2 * w)), np.uint8)
+    except zlib.error:
+        return None
+    if raw.size != h * (1 + 2 * w):
+        return None
+    raw = raw.reshape(h, 1 + 2 * w)
+    ft, rows = raw[:, 0], raw[:, 1:]
+    if (ft > 2).any():
+        return None
+    if (ft == 1).all():                                           # this package's writer: one GIL-free call
+        out = np.cumsum(rows.reshape(h, w, 2), axis=1, dtype=np.uint8).reshape(h, 2 * w)
+    else:
+        out = np.empty_like(rows)
+        prev = np.zeros(2 * w, np.uint8)
+        for r in range(h):
+            if ft[r] == 2:
+                np.add(rows[r], prev, out=out[r])
+            elif ft[r] == 0:
+                out[r] = rows[r]
+            else:                                                 # sub: running sum per byte lane (2 bytes per pixel)
+                out[r] = np.cumsum(rows[r].reshape(w, 2), axis=0, dtype=np.uint8).reshape(-1)
+            prev = out[r]
+    return np.ascontiguousarray(out).view(">u2").astype(np.uint16)
+
+
 def read_png16(path) -> np.ndarray:
+    with open(str(path), "rb") as f:
+        data = f.read()
+    a = _decode_png16_fast(data)
+    if a is not None:
+        return a
+    import io
     from PIL import Image
-    with Image.open(str(path)) as im:
+    with Image.open(io.BytesIO(data)) as im:
         a = np.asarray(im)
     if a.ndim == 3:
         a = a[..., 0]
     return a.astype(np.uint16) if a.dtype != np.uint16 else a
+
+
+def prefetch_map(fn, items, workers: int = None, lookahead: int = None):
+    """yield fn(item) for every item, in order, computing up to `lookahead` of them ahead on a thread pool"""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    if workers is None:
+        env = os.environ.get("V3D_PNG_THREADS")
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 4
+        workers = int(env) if env else max(1, min(8, ncpu))
+    lookahead = lookahead or 2 * workers
+    with ThreadPoolExecutor(workers, thread_name_prefix="v3d-read") as ex:
+        q, it = deque(), iter(items)
+        for x in it:
+            q.append(ex.submit(fn, x))
+            if len(q) >= lookahead:
+                break
+        while q:
+            r = q.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                q.append(ex.submit(fn, nxt))
+            yield r
