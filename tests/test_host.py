@@ -286,3 +286,39 @@ def test_png16_encoder_roundtrip_and_pool(tmp_path):
     with pytest.raises(OSError):
         pool.close()
     assert (tmp_path / "ok.png").exists()
+
+
+def test_png16_decoder_paths(tmp_path):
+    """own files take the single-call decoder; rows mixing none / sub / up take the row loop; Pillow-written files
+    (adaptive filters), 8-bit and RGB PNGs fall back to Pillow -- all give the same samples; prefetch keeps order"""
+    import struct, zlib
+    from PIL import Image
+    from video_3d_pipeline.utils import _decode_png16_fast, encode_png16, read_png16, prefetch_map
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 65536, (23, 31), dtype=np.uint16)
+    assert np.array_equal(_decode_png16_fast(encode_png16(a)), a)
+    # hand-built file: row r uses filter r % 3
+    be = a.astype(">u2").view(np.uint8).reshape(23, 62)
+    raw = np.zeros((23, 63), np.uint8)
+    for r in range(23):
+        f = r % 3
+        raw[r, 0] = f
+        if f == 0: raw[r, 1:] = be[r]
+        elif f == 1: raw[r, 1:3] = be[r, :2]; raw[r, 3:] = be[r, 2:] - be[r, :-2]
+        else: raw[r, 1:] = be[r] - (be[r - 1] if r else 0)
+    def chunk(t, b): return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+    mixed = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 31, 23, 16, 0, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(raw.tobytes())) + chunk(b"IEND", b"")
+    assert np.array_equal(_decode_png16_fast(mixed), a)
+    (tmp_path / "mixed.png").write_bytes(mixed)
+    with Image.open(tmp_path / "mixed.png") as im:
+        assert np.array_equal(np.asarray(im).astype(np.uint16), a)          # an independent decoder agrees with the file
+    smooth = (np.add.outer(np.arange(40), np.arange(50)) * 300).astype(np.uint16)
+    Image.fromarray(smooth).save(tmp_path / "pil.png")                      # libpng-style adaptive filtering
+    assert np.array_equal(read_png16(tmp_path / "pil.png"), smooth)
+    Image.fromarray((smooth >> 8).astype(np.uint8)).save(tmp_path / "g8.png")
+    assert _decode_png16_fast((tmp_path / "g8.png").read_bytes()) is None
+    assert np.array_equal(read_png16(tmp_path / "g8.png"), (smooth >> 8).astype(np.uint16))
+    assert _decode_png16_fast(b"not a png") is None
+    assert list(prefetch_map(lambda v: v * v, range(23), workers=3, lookahead=4)) == [v * v for v in range(23)]
+    assert list(prefetch_map(lambda v: v, [], workers=2)) == []
