@@ -80,6 +80,12 @@ int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t*
    neighbour strip since create (0 = healthy; > 0 means results of that call are invalid) */
 int v3d_sgbm_sync_errors(v3d_sgbm* h);
 
+/* Runtime switch of the lock-step top-down pass (needs all its workgroups co-resident): enable = 0 makes later
+   compute calls use one launch per direction instead (same results, ~2x the SGM time); also synchronises and clears
+   the time-out counter.  What a host does after v3d_sgbm_sync_errors() > 0 on a GPU it shares with other jobs:
+   switch off, recompute the batch.  Both paths are GPU paths; there is no CPU fallback. */
+int v3d_sgbm_set_lockstep(v3d_sgbm* h, int enable);
+
 /* per-stage HIP-event timing on the caller's stream (what bench.py's `roofline` object reads):
    v3d_sgbm_profile(h, 1) resets and enables; run compute calls; synchronise the stream;
    v3d_sgbm_profile_read fills total_ms[stage] (n >= v3d_sgbm_profile_stage_count()) and returns the

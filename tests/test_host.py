@@ -322,3 +322,19 @@ def test_png16_decoder_paths(tmp_path):
     assert _decode_png16_fast(b"not a png") is None
     assert list(prefetch_map(lambda v: v * v, range(23), workers=3, lookahead=4)) == [v * v for v in range(23)]
     assert list(prefetch_map(lambda v: v, [], workers=2)) == []
+
+
+def test_lockstep_timeout_switches_mode_instead_of_failing(capsys):
+    """depth.py backend: a lock-step time-out flag makes the batch recompute with per-direction launches"""
+    from video_3d_pipeline.depth import HipStereoBackend
+
+    class FakeMatcher:
+        def __init__(self, errs): self.errs, self.off = errs, False
+        def sync_errors(self): return 0 if self.off else self.errs
+        def set_lockstep(self, on): self.off = not on
+
+    healthy, sick = FakeMatcher(0), FakeMatcher(5)
+    assert HipStereoBackend._lockstep_ok(healthy) is True and healthy.off is False
+    assert HipStereoBackend._lockstep_ok(sick) is False and sick.off is True
+    assert "over-subscribed" in capsys.readouterr().out
+    assert HipStereoBackend._lockstep_ok(sick) is True          # after the switch the handle reports healthy

@@ -290,3 +290,20 @@ def test_fuzz_geometry_parameters_content(native, oracle, seed):
     m.close()
     assert errs == 0
     assert not mismatch_report(got, want, f"seed {seed} {W}x{H} {kw}"), mismatch_report(got, want, f"seed {seed} {W}x{H} {kw}")
+
+
+def test_lockstep_runtime_switch(native, oracle):
+    """v3d_sgbm_set_lockstep: the per-direction launches and the lock-step pass give the same bits on one handle"""
+    W, H = 300, 90
+    L, R = textured_pair(W, H, seed=77)
+    want = oracle.sgbm_compute(L, R)
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=2)
+    a = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    m.set_lockstep(False)
+    b = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    assert m.sync_errors() == 0
+    m.set_lockstep(True)
+    c = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
+    assert m.sync_errors() == 0
+    m.close()
+    assert np.array_equal(a, want) and np.array_equal(b, want) and np.array_equal(c, want)

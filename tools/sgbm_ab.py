@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
 import numpy as np, torch
 from video_3d_pipeline import _native as N, synthetic as syn
-W, H = 1920, 1080
+W, H = int(os.environ.get("QB_W", "1920")), int(os.environ.get("QB_H", "1080"))
 B = int(os.environ.get("QB_BATCH", "8"))
 L, R = syn.gray_pair(W, H, 0)
 Ld = N.to_device(np.stack([L] * B)); Rd = N.to_device(np.stack([R] * B))

@@ -1374,6 +1374,16 @@ extern "C" int v3d_sgbm_sync_errors(v3d_sgbm* h)
     return e;
 }
 
+extern "C" int v3d_sgbm_set_lockstep(v3d_sgbm* h, int enable)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    V3D_HIP_CHECK(hipSetDevice(h->device));
+    V3D_HIP_CHECK(hipDeviceSynchronize());
+    V3D_HIP_CHECK(hipMemset(h->vdd_err, 0, sizeof(int)));
+    h->vdd_mode = (enable && h->vdd_mf4 >= 1 && h->vdd_mf8 >= 1) ? 1 : 0;
+    return V3D_OK;
+}
+
 extern "C" int v3d_sgbm_profile(v3d_sgbm* h, int enable)
 {
     if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }

@@ -22,7 +22,7 @@ EXPORTS = (
     "v3d_depth_to_u16", "v3d_guided_upscale_ws_bytes", "v3d_guided_upscale", "v3d_bgr_to_gray",
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
     "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch",
-    "v3d_sgbm_sync_errors", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
+    "v3d_sgbm_sync_errors", "v3d_sgbm_set_lockstep", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
 )
 
 
@@ -63,6 +63,7 @@ def lib():
         L.v3d_sgbm_compute.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
         L.v3d_sgbm_profile.argtypes = [vp, ci]
         L.v3d_sgbm_sync_errors.argtypes = [vp]
+        L.v3d_sgbm_set_lockstep.argtypes = [vp, C.c_int]
         L.v3d_sgbm_profile_stage_name.argtypes = [ci]
         L.v3d_sgbm_profile_stage_name.restype = C.c_char_p
         L.v3d_sgbm_profile_read.argtypes = [vp, C.POINTER(C.c_double), ci]
@@ -163,6 +164,11 @@ class StereoSGBM:
     def sync_errors(self):
         """device-synchronise; number of lock-step (k_vdd) workgroups that timed out on a neighbour (0 = healthy)"""
         return int(lib().v3d_sgbm_sync_errors(self._h))
+
+    def set_lockstep(self, enable: bool):
+        """switch the co-resident lock-step pass on/off for later compute() calls (off = one launch per direction);
+        synchronises and clears the time-out counter"""
+        _check(lib().v3d_sgbm_set_lockstep(self._h, int(bool(enable))), "v3d_sgbm_set_lockstep")
 
     def profile(self, enable=True):
         """per-stage HIP-event timing on the current stream: enable, run compute(), synchronize, read_profile()"""

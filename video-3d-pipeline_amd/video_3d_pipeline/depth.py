@@ -52,13 +52,18 @@ class HipStereoBackend:
         return self._matcher
 
     @staticmethod
-    def _check_lockstep(matcher):
-        """the lock-step SGM kernel needs all its workgroups resident at once; if another process is hogging the
-        GPU its bounded spins give up and it raises a flag -- fail loudly rather than return a wrong disparity"""
+    def _lockstep_ok(matcher) -> bool:
+        """The lock-step SGM kernel needs all its workgroups resident at once; if another process is hogging the GPU
+        its bounded spins give up and raise a flag.  Then the batch is recomputed with one launch per direction
+        (still on the GPU, ~2x the SGM time, same bits) and the handle stays in that mode -- never a wrong disparity,
+        never a CPU path."""
         n = matcher.sync_errors()
-        if n:
-            raise RuntimeError(f"SGM lock-step kernel timed out waiting for neighbour strips ({n} workgroups): the GPU is "
-                               "over-subscribed; re-run with V3D_VDD=0 or without other jobs on this device")
+        if n == 0:
+            return True
+        print(f"warning: SGM lock-step kernel timed out waiting for neighbour strips ({n} workgroups): the GPU is "
+              "over-subscribed; recomputing this batch and continuing with one launch per direction")
+        matcher.set_lockstep(False)
+        return False
 
     def split_sbs(self, sbs_frame: np.ndarray, unsqueeze: bool):
         d = self.native.to_device(sbs_frame, self.device)
@@ -77,9 +82,12 @@ class HipStereoBackend:
             rg[i] = nat.bgr_to_gray(nat.to_device(r, self.device))
         matcher = self._get_matcher(W, H, n)
         disp = matcher.compute(lg, rg)
+        if not self._lockstep_ok(matcher):
+            disp = matcher.compute(lg, rg)
+            if matcher.sync_errors():
+                raise RuntimeError("SGM kernels report time-outs with the lock-step pass off: device fault")
         depth = nat.disp_to_depth(disp)
         out = depth.cpu().numpy()
-        self._check_lockstep(matcher)
         return [out[i] for i in range(n)]
 
     def _staging(self, key, shape, dtype, pinned):
@@ -110,8 +118,11 @@ class HipStereoBackend:
         nat.sbs_to_gray_batch(dev, unsqueeze, (lg, rg))
         matcher = self._get_matcher(ow, H, n)
         disp = matcher.compute(lg, rg, self._staging("disp", (n, H, ow), torch.int16, False))
+        if not self._lockstep_ok(matcher):
+            disp = matcher.compute(lg, rg, self._staging("disp", (n, H, ow), torch.int16, False))
+            if matcher.sync_errors():
+                raise RuntimeError("SGM kernels report time-outs with the lock-step pass off: device fault")
         depth = nat.disp_to_depth(disp, self._staging("depth", (n, H, ow), torch.float32, False))
-        self._check_lockstep(matcher)
         return depth
 
     def depth_to_host(self, depth) -> np.ndarray:
