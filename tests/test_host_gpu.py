@@ -72,3 +72,25 @@ def test_cli_runs_on_gpu(native, tmp_path, clip, capsys):
     assert len(dirs) == 1 and len(os.listdir(tmp_path / "cli" / dirs[0])) == 2
     rc = upscale.main([str(tmp_path / "cli" / dirs[0]), path, "--output", str(tmp_path / "o.mp4")])
     assert rc == 0
+
+
+def test_bench_line_contract(native):
+    """bench.py prints ONE JSON line with the keys the driver reads (metric/value/unit/..., roofline, cpu_baseline)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 0 and d["lockstep_timeouts"] == 0
