@@ -370,13 +370,23 @@ __device__ __forceinline__ void wta_pixel(const unsigned char* srow, bool valid,
         const uint4 t = *reinterpret_cast<const uint4*>(srow + q * 16);
         v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
-    uint32_t kmin = 0xFFFFFFFFu;
+    // argmin with the lowest d winning ties, in packed 16-bit arithmetic: (1) min S over the 64 halves; (2) keys
+    // (S - minS) * 64 + d with saturation (only keys < 64, i.e. S == minS, can win) and their packed minimum.
+    // 4 packed ops per two disparities instead of 6 scalar ones.
+    uint32_t mpk = v[0];
+#pragma unroll
+    for (int i = 1; i < 32; i++) mpk = pk_minu(mpk, v[i]);
+    const int minS = (int)min(mpk & 0xFFFFu, mpk >> 16);
+    const uint32_t minpk = pk_bcast(minS), k64 = 0x00400040u;
+    uint32_t kacc = 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < 32; i++) {
-        kmin = min(kmin, ((v[i] & 0xFFFFu) << 6) | (uint32_t)(2 * i));
-        kmin = min(kmin, ((v[i] >> 16) << 6) | (uint32_t)(2 * i + 1));
+        uint32_t key;
+        const uint32_t t = pk_subu_sat(v[i], minpk), dc = (uint32_t)(2 * i) | ((uint32_t)(2 * i + 1) << 16);
+        asm("v_pk_mad_u16 %0, %1, %2, %3 clamp" : "=v"(key) : "v"(t), "v"(k64), "s"(dc));
+        kacc = pk_minu(kacc, key);
     }
-    const int minS = (int)(kmin >> 6), best = (int)(kmin & 63u);
+    const int best = (int)(min(kacc & 0xFFFFu, kacc >> 16) & 63u);
     // uniqueness: reject iff exists d, |d-best| > 1, S[d]*(100-uniq) < minS*100  <=>  S[d] < T1
     const int uq = 100 - a.uniq, thr = minS * 100;
     int T1 = uq > 0 ? (thr + uq - 1) / uq : (thr > 0 ? 32768 : 0);
