@@ -2,8 +2,10 @@
 //
 // Replaces cv2.StereoSGBM_create(...).compute(left_gray, right_gray) as invoked at
 // reference depth.py:315-325, 341 (OpenCV MODE_SGBM 5-path default, MODE_HH 8-path optional).
-// Stage map: a-4 k_prefilter + k_cost, a-5 k_chain<...> (one launch per path
-// direction), a-6 the WTA tail of the last k_chain, a-7 k_lrcheck, a-8 k_median3x3 + k_ccl_*.
+// Stage map: a-4 k_prefilter + k_cost; a-5 k_vdd (the three top-down paths in one lock-step
+// pass) + k_hfused (both horizontal paths), a-6 the WTA tail of k_hfused; a-7/a-8 k_lrcheck_median + k_ccl_*.
+// k_chain<...> (one launch per path direction, WTA tail on the last) is the fallback behind V3D_VDD=0 /
+// V3D_HFUSED=0 / v3d_sgbm_set_lockstep(h, 0) and is parity-tested like the default path.
 //
 // HBM layout (per frame, W1 = W - 64):
 //   rec        : uint4 [H][W]        pre-filter records, left then right image: {grad, grad_lo, grad_hi, 0 | raw, raw_lo, raw_hi, 0}
