@@ -337,7 +337,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16 (SGM) + f32 (guided filter)", "data": "synthetic",
+            "dtype": "int16 (SGM) + f64 (guided filter sums; f32 depth in/out)", "data": "synthetic",
             "config": {"workload": ("configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth" if args.workload == "full"
                                     else "configs[1]: 1920x1080 SBS -> disparity (SBS split + SGBM + depth), no upscale"),
                        "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_HH (8 paths)" if args.sgbm_mode == "hh" else "MODE_SGBM (5 paths)",
