@@ -6,15 +6,24 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of `--batch` (default 8 = the reference's
-batch_size, depth.py:27) synthetic SBS frames already resident in HBM: v3d_sbs_to_gray ->
-v3d_sgbm_compute_batch -> v3d_disp_to_depth -> v3d_guided_upscale against the 4K guide -> float32 4K depth
-in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the
-only collective is the 4K guide round broadcast from rank 0 (RCCL), double-buffered on a side stream.
-Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (largest summed duration, HIP events on the
-launch stream); `cpu_baseline` = the CPU oracle (a port of the reference's OpenCV path) on one frame.
+One "step" = one pass of the hot path over one batch of `--batch` synthetic SBS frames (default 30 = what one
+co-resident lock-step k_vdd launch holds at 1080p; the reference's own batch_size is 8, depth.py:27 -- the same path at
+batch 8 is reported under `e2e.batch8` and `extra.batch8_hbm_resident`) already resident in HBM:
+v3d_sbs_to_gray -> v3d_sgbm_compute_batch -> v3d_disp_to_depth -> v3d_guided_upscale against the 4K guide -> float32 4K
+depth in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the only
+collective is the 4K guide round from rank 0 (RCCL), double-buffered on a side stream and ordered BEHIND the lock-step
+SGM pass of the step it overlaps (v3d_sgbm_stream_wait_lockstep).  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step  HBM-resident whole-job rate (the contract's timed region)
+  roofline             the dominant kernel (largest summed duration, HIP events on the launch stream)
+  cpu_baseline         the CPU oracle (a port of the reference's OpenCV path) on one frame + one frame per host core
+  parity_check         the timed region's own output (frame 0 of the last step) against that oracle; non-zero exit on mismatch
+  e2e                  SURVEY 8(d) config (3) as specified: pinned host SBS + guide in -> kernels -> pinned host f32 4K depth
+                       out, three streams, double-buffered; frames/s and per-batch latency, at the bench batch and at batch 8
+  extra                (N = 1, --workload all, the default) configs[1] disparity only, configs[3] correlation lookup, MODE_HH
 """
 import argparse
+import glob
 import json
 import os
 import statistics
@@ -32,6 +41,8 @@ import torch  # noqa: E402
 W, H, D = 1920, 1080, 64
 SCALE = 2
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+GF_R, GF_EPS = 8, 1e-3
+N_DISTINCT = 8                  # distinct synthetic frames per rank, cycled through the batch
 
 
 def alg_bytes_per_frame():
@@ -53,7 +64,8 @@ def alg_bytes_per_frame():
 
 def cpu_baseline(sbs, guide):
     """the oracle (kind 'port': C restatement of the OpenCV path depth.py drives) on ONE frame of the same
-    workload, single thread; plus real OpenCV if the box happens to have it (it does not in this image)."""
+    workload, single thread; plus real OpenCV if the box happens to have it (it does not in this image).
+    Returns (json object, oracle disp16 of the frame, oracle f64 4K depth of the frame) -- the last two feed parity_check."""
     from oracle import oracle as O
     O.lib()
     t0 = time.perf_counter()
@@ -62,7 +74,7 @@ def cpu_baseline(sbs, guide):
     disp = O.sgbm_compute(gl, gr)
     t2 = time.perf_counter()
     depth = O.disp_to_depth(disp)
-    O.guided_upscale(depth, guide, 8, 1e-3)
+    q = O.guided_upscale(depth, guide, GF_R, GF_EPS)
     t3 = time.perf_counter()
     total = t3 - t0
     out = {"value": 1.0 / total, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -76,7 +88,7 @@ def cpu_baseline(sbs, guide):
         if nthr > 1:
             def one(_):
                 l, r = O.sbs_to_gray(sbs, True)
-                O.guided_upscale(O.disp_to_depth(O.sgbm_compute(l, r)), guide, 8, 1e-3)
+                O.guided_upscale(O.disp_to_depth(O.sgbm_compute(l, r)), guide, GF_R, GF_EPS)
             t6 = time.perf_counter()
             with ThreadPoolExecutor(nthr) as ex:
                 list(ex.map(one, range(nthr)))
@@ -96,40 +108,148 @@ def cpu_baseline(sbs, guide):
                          "oracle_mismatch_px": int((ref != disp).sum())}
     except ImportError:
         out["opencv"] = "unavailable on this box: parity and CPU baseline are vs this repo's restatement"
-    return out
+    return out, disp, q
 
 
-def bench_corr(args, N):
+def bench_corr(args, N, dev):
     """BASELINE configs[3]: CREStereo-style correlation lookup, bf16 in / f32 accumulate on MFMA, 1080p/4 features"""
     h, w, C, G = 270, 480, 256, 4
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
     fl = torch.randn((h, w, C), device=dev).to(torch.bfloat16)
     fr = torch.randn((h, w, C), device=dev).to(torch.bfloat16)
     flow = torch.rand((2, h, w), device=dev) * 4 - 2
-    for _ in range(args.warmup):
+    steps = max(args.steps, 20)
+    for _ in range(max(args.warmup, 3)):
         N.corr_lookup(fl, fr, flow, G, 0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         N.corr_lookup(fl, fr, flow, G, 0)
     e1.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ms = e0.elapsed_time(e1) / args.steps
+    ms = e0.elapsed_time(e1) / steps
     alg = 2 * h * w * C * 2 + 2 * h * w * 4 + G * 9 * h * w * 4           # fl + fr bf16, flow, out f32 (SURVEY 8d: ~142 MB form A)
     flops = 2.0 * h * w * C * 9
-    print(json.dumps({"metric": "corr_lookups_per_s", "value": args.steps / el, "unit": "lookups/s", "n_gpus": 1,
-                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-                      "vs_baseline": None, "dtype": "bf16 in / f32 accumulate (MFMA 16x16x32)", "data": "synthetic",
-                      "config": {"workload": "configs[3]: correlation lookup 270x480x256, 4 groups x 9 offsets (1x9)"},
-                      "roofline": {"bound": "hbm", "kernel": "k_corr_warp + k_corr<0>", "achieved": alg / (ms * 1e-3) / 1e9,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                   "useful_gflops": flops / (ms * 1e-3) / 1e9,
-                                   "note": "AI ~ 4 flop/B: HBM/L2 bound; MFMA only removes the VALU bottleneck"},
-                      "cpu_baseline": None}))
+    return {"metric": "corr_lookups_per_s", "value": steps / el, "unit": "lookups/s", "n_gpus": 1,
+            "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 in / f32 accumulate (MFMA 16x16x32)", "data": "synthetic",
+            "config": {"workload": "configs[3]: correlation lookup 270x480x256, 4 groups x 9 offsets (1x9)"},
+            "roofline": {"bound": "hbm", "kernel": "k_corr_warp + k_corr<0>", "achieved": alg / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "useful_gflops": flops / (ms * 1e-3) / 1e9,
+                         "note": "AI ~ 4 flop/B: HBM/L2 bound; MFMA only removes the VALU bottleneck"},
+            "cpu_baseline": None}
+
+
+def latest_traffic():
+    """HBM traffic per kernel from the newest committed rocprofv3 --pmc passes (profiles/rNN_traffic.json)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError):
+        return None, None
+
+
+class HotPath:
+    """device buffers + the matcher of one rank; step() enqueues one pass over a batch on the current stream"""
+
+    def __init__(self, N, dev, B, mode):
+        self.N, self.dev, self.B = N, dev, B
+        Hh, Wh = H * SCALE, W * SCALE
+        self.lg = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        self.rg = torch.empty_like(self.lg)
+        self.disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+        self.depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        self.out4k = torch.empty((B, Hh, Wh), dtype=torch.float32, device=dev)
+        self.matcher = N.StereoSGBM(W, H, B, device=dev, mode=mode)
+        self.gf_ev = []
+
+    def step(self, sbs, guides, out4k=None, upscale=True, timed=False):
+        N, n = self.N, sbs.shape[0]
+        N.sbs_to_gray_batch(sbs, True, (self.lg[:n], self.rg[:n]))
+        self.matcher.compute(self.lg[:n], self.rg[:n], self.disp[:n])
+        N.disp_to_depth(self.disp[:n], self.depth[:n])
+        if not upscale:
+            return
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        N.guided_upscale_batch(self.depth[:n], guides, GF_R, GF_EPS, self.out4k[:n] if out4k is None else out4k)
+        if timed:
+            e1.record()
+            self.gf_ev.append((e0, e1))
+
+
+def run_e2e(hp, h_sbs, h_gui, nb, steps, warmup):
+    """SURVEY 8(d) config (3) as specified: SBS frames + 4K guides start in PINNED HOST memory, the float32 4K depth ends in
+    pinned host memory.  Three streams (H2D, compute, D2H), double-buffered device and host tensors: step s+1's inputs
+    upload and step s-1's result downloads while step s computes.  Per-step events give a real per-batch latency
+    (first H2D byte -> last D2H byte) next to the throughput."""
+    dev = hp.dev
+    Hh, Wh = H * SCALE, W * SCALE
+    h_sbs, h_gui = h_sbs[:nb], h_gui[:nb]
+    h_out = [torch.empty((nb, Hh, Wh), dtype=torch.float32).pin_memory() for _ in range(2)]
+    d_sbs = [torch.empty((nb, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_gui = [torch.empty((nb, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_out = [torch.empty((nb, Hh, Wh), dtype=torch.float32, device=dev) for _ in range(2)]
+    s_in, s_out, s_cmp = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+
+    def run(nsteps):
+        in_ready, cmp_done, out_done = [None, None], [None, None], [None, None]
+        t_in, t_done = [], []
+
+        def upload(s):
+            k = s & 1
+            with torch.cuda.stream(s_in):
+                if cmp_done[k] is not None:
+                    s_in.wait_event(cmp_done[k])           # step s-2 has consumed this input slot
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(s_in)
+                t_in.append(e0)
+                d_sbs[k].copy_(h_sbs, non_blocking=True)
+                d_gui[k].copy_(h_gui, non_blocking=True)
+                e = torch.cuda.Event()
+                e.record(s_in)
+                in_ready[k] = e
+        upload(0)
+        for s in range(nsteps):
+            k = s & 1
+            if s + 1 < nsteps:
+                upload(s + 1)
+            s_cmp.wait_event(in_ready[k])
+            if out_done[k] is not None:
+                s_cmp.wait_event(out_done[k])              # step s-2's result has left this output slot
+            hp.step(d_sbs[k], d_gui[k], out4k=d_out[k])
+            e = torch.cuda.Event()
+            e.record(s_cmp)
+            cmp_done[k] = e
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(e)
+                h_out[k].copy_(d_out[k], non_blocking=True)
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record(s_out)
+                out_done[k] = e2
+                t_done.append(e2)
+        torch.cuda.synchronize()
+        return t_in, t_done
+
+    run(warmup)
+    t0 = time.perf_counter()
+    t_in, t_done = run(steps)
+    el = time.perf_counter() - t0
+    lat = [a.elapsed_time(b) for a, b in zip(t_in, t_done)]
+    gaps = [t_done[i].elapsed_time(t_done[i + 1]) for i in range(len(t_done) - 1)]
+    mb = (h_sbs.numel() + h_gui.numel() + h_out[0].numel() * 4) / nb / 1e6
+    fps = nb * steps / el
+    return {"value": fps, "unit": "frames/s", "frames_per_step": nb, "steps": steps,
+            "latency_p50_ms_per_batch": statistics.median(lat), "latency_max_ms_per_batch": max(lat),
+            "p50_ms_per_step": statistics.median(gaps) if gaps else el / steps * 1e3,
+            "p50_ms_per_frame": (statistics.median(gaps) if gaps else el / steps * 1e3) / nb,
+            "link_MB_per_frame": mb, "link_GBps": fps * mb / 1e3}
 
 
 def main():
@@ -138,23 +258,21 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=30,
-                    help="frames per step per GPU (the reference's --batch-size; 30 = what one lock-step k_vdd launch holds co-resident)")
+                    help="frames per step per GPU (the reference's --batch-size is 8; 30 = what one lock-step k_vdd launch holds co-resident)")
     ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="auto",
                     help="how rank 0 hands out the 4K guide rounds: broadcast the whole round (north_star), scatter each rank's "
                          "frames (world x fewer bytes), or auto = broadcast if it hides behind one compute step, else scatter")
-    ap.add_argument("--workload", choices=["full", "sgbm", "corr"], default="full",
-                    help="full = BASELINE configs[2] (default, the headline metric); sgbm = configs[1] (disparity only); "
-                         "corr = configs[3] (bf16 MFMA correlation lookup, 270x480x256 features)")
+    ap.add_argument("--workload", choices=["all", "full", "sgbm", "corr"], default="all",
+                    help="all (default) = the headline line of `full` + `extra` {sgbm_only, corr, hh, batch8} at N = 1; full = BASELINE "
+                         "configs[2] only; sgbm = configs[1] (disparity only) as the line; corr = configs[3] (bf16 MFMA correlation lookup)")
     ap.add_argument("--sgbm-mode", choices=["sgbm", "hh"], default="sgbm",
                     help="sgbm = OpenCV MODE_SGBM, 5 paths (what depth.py:315-325 gets by default); hh = MODE_HH, 8 paths")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (then no parity_check either)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive pipeline leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
 
     from video_3d_pipeline import _native as N, sharding, synthetic as syn
-    if args.workload == "corr":
-        return bench_corr(args, N)
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -166,44 +284,52 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)         # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    N.lib()
+    if args.workload == "corr":
+        print(json.dumps(bench_corr(args, N, dev)))
+        return 0
     if world > 1:
         sharding.init_process_group(args.dist_backend)
-    N.lib()
     B = args.batch
+    full = args.workload in ("all", "full")
 
-    # ---- synthetic inputs (two distinct frames, tiled to the batch), resident in HBM ----
-    base_sbs = [syn.sbs_frame(W, H, 2 * rank + i) for i in range(2)]
-    base_guide = [syn.guide_frame(W, H, 2 * rank + i, SCALE) for i in range(2)]
-    sbs = torch.from_numpy(np.stack([base_sbs[i % 2] for i in range(B)])).to(dev)
-    guide_own = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)
+    # ---- synthetic inputs: N_DISTINCT distinct frames per rank, cycled through the batch, resident in HBM ----
+    nd = min(B, N_DISTINCT)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def synth(i):
+        return syn.sbs_frame(W, H, nd * rank + i), syn.guide_frame(W, H, nd * rank + i, SCALE)
+    with ThreadPoolExecutor(min(nd, max(1, len(os.sched_getaffinity(0)) // max(world, 1)))) as ex:
+        base = list(ex.map(synth, range(nd)))
+    base_sbs, base_guide = [b[0] for b in base], [b[1] for b in base]
+    h_sbs = torch.from_numpy(np.stack([base_sbs[i % nd] for i in range(B)]))
+    h_gui = torch.from_numpy(np.stack([base_guide[i % nd] for i in range(B)]))
+    sbs = h_sbs.to(dev)
+    guide_own = h_gui.to(dev)
     Hh, Wh = H * SCALE, W * SCALE
     # guide rounds: round j holds the guide frames of global frames j*world .. j*world+world-1 (rank r owns slot r)
     mode = {"v": args.guide_exchange}
     exch_info = {}
     scatter_cache = {}
-    if world > 1 and args.guide_exchange != "none":
-        rounds_src = torch.from_numpy(np.stack([base_guide[i % 2] for i in range(B)])).to(dev)      # [B,Hh,Wh]
-        rounds_src = rounds_src[:, None].expand(B, world, Hh, Wh).contiguous() if rank == 0 else None
+    guide_buf, side, rounds_src = None, None, None
+    if world > 1 and args.guide_exchange != "none" and full:
+        rounds_src = guide_own[:, None].expand(B, world, Hh, Wh).contiguous() if rank == 0 else None
         side = torch.cuda.Stream(device=dev)
-        guide_buf = None
 
         def alloc_bufs():
             return [torch.empty((B, world, Hh, Wh), dtype=torch.uint8, device=dev) if mode["v"] == "broadcast"
                     else torch.empty((B, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(2)]
-    else:
-        rounds_src, guide_buf, side = None, None, None
 
-    lg = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    rg = torch.empty_like(lg)
-    disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
-    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    out4k = torch.empty((B, Hh, Wh), dtype=torch.float32, device=dev)
-    matcher = N.StereoSGBM(W, H, B, device=local, mode=1 if args.sgbm_mode == "hh" else 0)
+    hp = HotPath(N, dev, B, 1 if args.sgbm_mode == "hh" else 0)
+    matcher = hp.matcher
 
     def exchange(slot):
-        """enqueue the guide exchange for the NEXT step on the side stream"""
+        """enqueue the guide exchange for the NEXT step on the side stream, ordered behind the lock-step SGM pass of the
+        step just enqueued on the main stream: RCCL's workgroups then never take CU slots that pass was sized with (they
+        overlap the horizontal pass, the post-filters and the upscale instead); the next step waits for the exchange."""
         if guide_buf is None:
             return None
+        matcher.stream_wait_lockstep(side)
         with torch.cuda.stream(side):
             if mode["v"] == "broadcast":
                 # the root sends straight from the decoded round (no staging copy), the others receive into the slot
@@ -225,22 +351,6 @@ def main():
             return (rounds_src if rank == 0 else guide_buf[slot])[:, rank]
         return guide_buf[slot]
 
-    gf_ev = []
-
-    def step(guides, timed):
-        N.sbs_to_gray_batch(sbs, True, (lg, rg))
-        matcher.compute(lg, rg, disp)
-        N.disp_to_depth(disp, depth)
-        if args.workload == "sgbm":
-            return
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        N.guided_upscale_batch(depth, guides, 8, 1e-3, out4k)
-        if timed:
-            e1.record()
-            gf_ev.append((e0, e1))
-
     def run(nsteps, timed):
         evs = []
         pending = exchange(0)
@@ -248,59 +358,79 @@ def main():
             slot = s & 1
             if pending is not None:
                 torch.cuda.current_stream().wait_event(pending)
-            nxt = exchange(1 - slot) if s + 1 < nsteps else None
             if timed:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 evs.append(e)
-            step(my_guides(slot), timed)
-            pending = nxt
+            hp.step(sbs, my_guides(slot), upscale=full, timed=timed)
+            pending = exchange(1 - slot) if s + 1 < nsteps else None          # after the step: its k_vdd event is the one to order behind
         if timed:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             evs.append(e)
         return evs
 
-    if world > 1 and args.guide_exchange != "none":
+    if side is not None:
         if args.guide_exchange == "auto":
             # time one compute step and one full-round broadcast; keep the broadcast only if it hides behind the step
             mode["v"] = "broadcast"
             guide_buf = alloc_bufs()
-            step(guide_own, False); torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter(); step(guide_own, False); torch.cuda.synchronize(); t_step = time.perf_counter() - t0
+            hp.step(sbs, guide_own); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter(); hp.step(sbs, guide_own); torch.cuda.synchronize(); t_step = time.perf_counter() - t0
             exchange(0); torch.cuda.synchronize(); dist.barrier()
             t0 = time.perf_counter(); exchange(0); torch.cuda.synchronize(); dist.barrier(); t_bc = time.perf_counter() - t0
             tt = torch.tensor([t_step, t_bc], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_step, t_bc = float(tt[0]), float(tt[1])
             exch_info = {"step_ms": t_step * 1e3, "broadcast_ms": t_bc * 1e3}
-            if t_bc > 0.8 * t_step:
+            if t_bc > 0.5 * t_step:              # the exchange window is the part of a step behind k_vdd (about 60 % of it)
                 mode["v"] = "scatter"
                 guide_buf = None
                 torch.cuda.empty_cache()
         if guide_buf is None:
             guide_buf = alloc_bufs()
-    run(args.warmup, False)
-    torch.cuda.synchronize()
-    matcher.profile(True)
+
+    def timed_region():
+        run(args.warmup, False)
+        torch.cuda.synchronize()
+        matcher.profile(True)
+        hp.gf_ev.clear()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs = run(args.steps, True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return evs, time.perf_counter() - t0
+
+    evs, elapsed = timed_region()
+    # a lock-step pass that timed out (GPU shared with another job) invalidated its outputs on the device: such a run is
+    # not a measurement.  Do what depth.py does -- switch the handle to per-direction launches -- and time again.
+    timeouts = matcher.sync_errors()
+    recomputed = False
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    evs = run(args.steps, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        t = torch.tensor([timeouts], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        any_timeouts = int(t.item())
+    else:
+        any_timeouts = timeouts
+    if any_timeouts > 0:
+        matcher.set_lockstep(False)
+        recomputed = True
+        evs, elapsed = timed_region()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    rc = 0
     if rank == 0:
         step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
         calls, stage_ms = matcher.read_profile()
+        matcher.profile(False)
         sg, gf = alg_bytes_per_frame()
         if stage_ms.get("chain_h0", 0.0) / max(calls, 1) < 0.02:     # both horizontal paths run inside the fused last launch
             sg["chain_h4_wta"] += sg["chain_h0"]
@@ -315,57 +445,149 @@ def main():
         for name, total in stage_ms.items():
             if calls and total > 0:
                 kernels[name] = {"avg_ms": total / calls, "alg_bytes": sg.get(name, 0) * B}
-        gfa = sum(a.elapsed_time(b) for a, b in gf_ev) / max(len(gf_ev), 1) if gf_ev else 1e-9
-        kernels["guided_sweep1+2"] = {"avg_ms": gfa, "alg_bytes": gf["guided_sweep1+2"] * B}    # launch pair over the batch
+        gfa = 0.0
+        if full:
+            gfa = sum(a.elapsed_time(b) for a, b in hp.gf_ev) / max(len(hp.gf_ev), 1) if hp.gf_ev else 1e-9
+            kernels["guided_upscale"] = {"avg_ms": gfa, "alg_bytes": gf["guided_sweep1+2"] * B}    # one launch (fused) or a launch pair over the batch
         dom = max((k for k in kernels if not k.startswith("guided")), key=lambda k: kernels[k]["avg_ms"])
         dk = kernels[dom]
         achieved = dk["alg_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9
-        traffic = None                     # PMC counters cannot be read in-process: taken from the committed rocprofv3 --pmc passes
-        try:
-            tfile = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            tj = tfile["kernels"]
-            if dom in tj:
-                traffic = int(tj[dom]["traffic_bytes"] * B / tfile.get("_frames_per_launch", 30))
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, tsrc = None, None          # PMC counters cannot be read in-process: taken from the committed rocprofv3 --pmc passes
+        tfile, tname = latest_traffic()
+        if tfile and dom in tfile.get("kernels", {}):
+            traffic = int(tfile["kernels"][dom]["traffic_bytes"] * B / tfile.get("_frames_per_launch", 30))
+            tsrc = tname + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
         sgbm_ms = sum(v["avg_ms"] for k, v in kernels.items() if not k.startswith("guided"))
         sgbm_alg = sum(sg.values()) * B
+        full_alg = sgbm_alg + (gf["guided_sweep1+2"] * B if full else 0)
+        p50_step = statistics.median(step_ms)
         res = {
-            "metric": "1080p_sbs_to_4k_depth_frames_per_s" if args.workload == "full" else "1080p_sbs_to_disparity_frames_per_s",
+            "metric": "1080p_sbs_to_4k_depth_frames_per_s" if full else "1080p_sbs_to_disparity_frames_per_s",
             "value": world * B * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 (SGM) + f64 (guided filter sums; f32 depth in/out)", "data": "synthetic",
-            "config": {"workload": ("configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth" if args.workload == "full"
+            "config": {"workload": ("configs[2]: full depth.py + upscale.py hot path, 1920x1080 SBS -> 3840x2160 guided-filter depth" if full
                                     else "configs[1]: 1920x1080 SBS -> disparity (SBS split + SGBM + depth), no upscale"),
-                       "frames_per_step_per_gpu": B, "numDisparities": D, "sgbm_mode": "MODE_HH (8 paths)" if args.sgbm_mode == "hh" else "MODE_SGBM (5 paths)",
-                       "guided_radius": 8, "guided_eps": 1e-3, "parallelism": f"frames round-robin over {world} GPU(s)",
-                       "guide_exchange": (mode["v"] if world > 1 else "local"), "guide_exchange_probe": exch_info},
-            "p50_ms_per_frame": statistics.median(step_ms) / B,
+                       "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": nd, "reference_batch_size": 8,
+                       "numDisparities": D, "sgbm_mode": "MODE_HH (8 paths)" if args.sgbm_mode == "hh" else "MODE_SGBM (5 paths)",
+                       "guided_radius": GF_R, "guided_eps": GF_EPS, "parallelism": f"frames round-robin over {world} GPU(s)",
+                       "guide_exchange": (mode["v"] if side is not None else "local"), "guide_exchange_probe": exch_info,
+                       "guide_exchange_order": "side stream, behind the step's lock-step SGM pass" if side is not None else None,
+                       "timed_region": "HBM-resident inputs and outputs (the contract); host-link-inclusive figures under e2e"},
+            "p50_ms_per_step": p50_step,
+            "p50_ms_per_frame": p50_step / B,
+            "p50_note": "amortised: median step time / frames per step; per-batch latencies are under e2e",
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                          "avg_launch_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"],
                          "sgbm_all_kernels": {"alg_bytes_per_batch": sgbm_alg, "ms_per_batch": sgbm_ms,
                                               "achieved": sgbm_alg / (sgbm_ms * 1e-3) / 1e9,
                                               "frac": sgbm_alg / (sgbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "guided_upscale": {"alg_bytes_per_frame": gf["guided_sweep1+2"], "ms_per_frame": gfa / B,
-                                            "achieved": gf["guided_sweep1+2"] / (gfa / B * 1e-3) / 1e9},
+                         "whole_step": {"alg_bytes_per_step": full_alg, "achieved": full_alg / (p50_step * 1e-3) / 1e9,
+                                        "frac": full_alg / (p50_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_launch": {k: round(v["avg_ms"], 4) for k, v in kernels.items()}},
         }
-        res["lockstep_timeouts"] = matcher.sync_errors()            # must be 0: k_vdd's bounded neighbour waits never tripped
+        if full:
+            res["roofline"]["guided_upscale"] = {"alg_bytes_per_frame": gf["guided_sweep1+2"], "ms_per_frame": gfa / B,
+                                                 "achieved": gf["guided_sweep1+2"] / (gfa / B * 1e-3) / 1e9,
+                                                 "frac": gf["guided_sweep1+2"] / (gfa / B * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        res["lockstep_timeouts"] = timeouts           # of the first attempt; > 0 means the timed region above is the per-direction rerun
+        res["lockstep_recomputed"] = recomputed
+        if recomputed:
+            res["lockstep_timeouts_after_switch"] = matcher.sync_errors()
+
+        # ---- the timed region's own output against the oracle (frame 0 of the last step is base frame 0) ----
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(base_sbs[0], base_guide[0])
+            cb, want_disp, want_q = cpu_baseline(base_sbs[0], base_guide[0])
+            res["cpu_baseline"] = cb
+            got_disp = hp.disp[0].cpu().numpy()
+            bad = int((got_disp != want_disp).sum())
+            pc = {"frame": 0, "disp_mismatch_px": bad, "disp_px": int(want_disp.size)}
+            # frames i and i + nd of the batch carry the same content: data-dependent kernels (CCL, atomicMin keys) must agree
+            pc["batch_repeats_identical"] = all(bool(torch.equal(hp.disp[i], hp.disp[i % nd])) for i in range(nd, B))
+            ok = bad == 0 and pc["batch_repeats_identical"]
+            if full:
+                got_q = hp.out4k[0].cpu().numpy().astype(np.float64)
+                rel = np.abs(got_q - want_q) / np.maximum(np.abs(want_q), 1e-6 * max(float(np.abs(want_q).max()), 1e-30))
+                pc["guided_max_rel"] = float(rel.max())
+                pc["guided_tolerance"] = 1e-3
+                pc["guided_repeats_identical"] = all(bool(torch.equal(hp.out4k[i], hp.out4k[i % nd])) for i in range(nd, B))
+                ok = ok and pc["guided_max_rel"] <= 1e-3 and pc["guided_repeats_identical"]
+            pc["ok"] = bool(ok)
+            res["parity_check"] = pc
+            if not ok:
+                rc = 3
         else:
             res["cpu_baseline"] = None
+            res["parity_check"] = None
+
+        # ---- SURVEY 8(d) config (3) as specified: host in -> host out, pipelined ----
+        if full and world == 1 and not args.no_e2e:
+            h_sbs_p, h_gui_p = h_sbs.pin_memory(), h_gui.pin_memory()
+            e2e_steps = max(4, min(args.steps, 12))
+            e2e = {"what": "pinned host SBS + 4K guide -> H2D -> hot path -> D2H -> pinned host f32 4K depth; 3 streams, double-buffered",
+                   "batch%d" % B: run_e2e(hp, h_sbs_p, h_gui_p, B, e2e_steps, 2)}
+            if B > 8:
+                e2e["batch8"] = run_e2e(hp, h_sbs_p, h_gui_p, 8, 2 * e2e_steps, 2)     # the reference's batch size (depth.py:27)
+            e2e["value"] = e2e["batch%d" % B]["value"]
+            e2e["unit"] = "frames/s"
+            e2e["p50_ms_per_frame"] = e2e["batch%d" % B]["p50_ms_per_frame"]
+            e2e["link_GBps"] = e2e["batch%d" % B]["link_GBps"]
+            e2e["lockstep_timeouts"] = matcher.sync_errors()
+            res["e2e"] = e2e
+
+        # ---- the other single-GPU configs of BASELINE.json, so that the driver's line carries them too ----
+        if args.workload == "all" and world == 1:
+            extra = {}
+            st = max(3, min(args.steps, 10))
+
+            def rate(fn, n_frames, nsteps):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(nsteps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / nsteps
+                return {"value": n_frames / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames_per_step": n_frames, "steps": nsteps}
+            r = rate(lambda: hp.step(sbs, guide_own, upscale=False), B, st)
+            r["config"] = "configs[1]: 1920x1080 SBS -> disparity (SBS split + SGBM + depth), no upscale"
+            r["alg_frac_of_8TBps"] = sum(alg_bytes_per_frame()[0].values()) * B / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            extra["sgbm_only"] = r
+            if B > 8:
+                r = rate(lambda: hp.step(sbs[:8], guide_own[:8]), 8, st)
+                r["config"] = "configs[2] at the reference's batch size 8 (depth.py:27), HBM-resident"
+                extra["batch8_hbm_resident"] = r
+            extra["lockstep_timeouts"] = matcher.sync_errors()
+            matcher.close()
+            hp.matcher = None
+            if args.sgbm_mode == "sgbm":
+                hh = N.StereoSGBM(W, H, B, device=dev, mode=1)
+                hp.matcher = hh
+                r = rate(lambda: hp.step(sbs, guide_own), B, st)
+                r["config"] = "configs[2] with MODE_HH (8 SGM paths)"
+                r["lockstep_timeouts"] = hh.sync_errors()
+                extra["hh"] = r
+                hh.close()
+                hp.matcher = None
+            c = bench_corr(args, N, dev)
+            extra["corr"] = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "config": c["config"]["workload"],
+                             "roofline": c["roofline"], "dtype": c["dtype"]}
+            res["extra"] = extra
         print(json.dumps(res))
-    matcher.close()
+    if hp.matcher is not None:
+        hp.matcher.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

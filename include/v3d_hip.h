@@ -11,6 +11,8 @@
  *   v3d_sgbm_create        depth.py:315-325 cv2.StereoSGBM_create(...)
  *   v3d_sgbm_compute[_batch]  depth.py:341 stereo.compute(left_gray, right_gray) -> int16 x16
  *   v3d_disp_to_depth      depth.py:341 .astype(float32)/16.0 and depth.py:374 clamp <=0 -> 0
+ *   v3d_mono_blend         depth.py:344-374 the "hybrid" blend: cv2.resize(mono) INTER_LINEAR, min-max to [0, 64],
+ *                          0.7 * disparity + 0.3 * mono, clamp <= 0 -> 0 (the mono map comes from the host: DPT or any provider)
  *   v3d_depth_to_u16       depth.py:397-406 save_depth_map min-max normalisation to uint16
  *   v3d_guided_upscale     upscale.py:21-73 upscale_depth_maps_ffmpeg (`scale` filter), re-specified
  *                          as guided-filter joint upsampling
@@ -38,6 +40,7 @@ extern "C" {
 #define V3D_ERR_ARG (-1)
 #define V3D_ERR_HIP (-2)
 #define V3D_ERR_UNSUPPORTED (-3)
+#define V3D_ERR_LOCKSTEP (-4)   /* a lock-step SGM pass timed out on an over-subscribed GPU: see v3d_sgbm_set_lockstep */
 
 #define V3D_MODE_SGBM 0   /* 5 paths, single pass: cv2.STEREO_SGBM_MODE_SGBM (the reference's default) */
 #define V3D_MODE_HH   1   /* 8 paths, two passes: cv2.STEREO_SGBM_MODE_HH */
@@ -76,15 +79,34 @@ int v3d_sgbm_compute_batch(v3d_sgbm* h, const uint8_t* left_gray, const uint8_t*
                            int n, int W, int H, int pitch, size_t frame_stride,
                            int16_t* disp16_out, void* stream);
 
-/* synchronises the device; returns the number of lock-step workgroups that timed out waiting for a
-   neighbour strip since create (0 = healthy; > 0 means results of that call are invalid) */
+/* Lock-step pass and an over-subscribed GPU.  The three top-down SGM paths run as ONE pass whose workgroups must all
+   be resident together (sized from the occupancy query at create time).  If another process or stream holds CUs, a
+   workgroup's bounded wait for its neighbour strip gives up.  The library then NEVER hands out those disparities:
+     - the last launch of the call sets every output pixel of the call to INVALID (-16) and raises a host-visible flag;
+     - every later v3d_sgbm_compute* on the handle returns V3D_ERR_LOCKSTEP until the host reacts;
+     - v3d_sgbm_poll_errors (no synchronisation) / v3d_sgbm_sync_errors (device synchronise) return the number of
+       workgroups that timed out since the state was last cleared (0 = healthy);
+     - v3d_sgbm_set_lockstep(h, 0) synchronises, clears the state and makes later calls use one launch per direction
+       (same bits, ~2x the SGM time); (h, 1) clears and keeps the lock-step pass.  Then recompute the batch.
+   Both paths are GPU paths; there is no CPU fallback. */
 int v3d_sgbm_sync_errors(v3d_sgbm* h);
-
-/* Runtime switch of the lock-step top-down pass (needs all its workgroups co-resident): enable = 0 makes later
-   compute calls use one launch per direction instead (same results, ~2x the SGM time); also synchronises and clears
-   the time-out counter.  What a host does after v3d_sgbm_sync_errors() > 0 on a GPU it shares with other jobs:
-   switch off, recompute the batch.  Both paths are GPU paths; there is no CPU fallback. */
+int v3d_sgbm_poll_errors(const v3d_sgbm* h);
 int v3d_sgbm_set_lockstep(v3d_sgbm* h, int enable);
+/* make `stream` (hipStream_t) wait until the lock-step pass of the latest compute call on `h` has finished.  A host
+   that runs a collective (RCCL) on a side stream orders it behind the pass with this call, and the next compute call
+   behind the collective: the collective's workgroups then never take CU slots the pass was sized with. */
+int v3d_sgbm_stream_wait_lockstep(v3d_sgbm* h, void* stream);
+
+/* Tuning switches of a handle (defaults = the measured best; results never change): "lockstep" 0/1, "hfused" 0/1,
+   "chain_dpl" 4/8, "vdd_dpl" 0/4/8, "cost_band" >= 8, "cost_xcd" / "vdd_xcd" / "hf_xcd" 0/1, "reserve_cus" (CUs other
+   streams keep busy during a lock-step pass), "vdd_spin_limit" (poll rounds per lane; 0 = derived from the row count).
+   get also knows the read-only "vdd_frames_per_launch_dpl4" / "_dpl8".  Unknown key or bad value: V3D_ERR_ARG.
+   The library reads no environment variables. */
+int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value);
+int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* value);
+/* library-wide switches of the handle-less entry points: "gf_band1", "gf_band2" (rows per workgroup of the guided
+   sweeps), "gf_tiled" 0/1 (force the LDS-tiled guided kernel), "corr_gather" 0/1 (fused gather-GEMM correlation) */
+int v3d_set_option(const char* key, int value);
 
 /* per-stage HIP-event timing on the caller's stream (what bench.py's `roofline` object reads):
    v3d_sgbm_profile(h, 1) resets and enables; run compute calls; synchronise the stream;
@@ -122,6 +144,17 @@ int v3d_split_sbs(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze
 int v3d_disp_to_depth(const int16_t* disp16, size_t n, float* depth_out, void* stream);
 /* minmax_ws: device scratch of >= 2 floats */
 int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, float* minmax_ws, void* stream);
+
+/* depth.py:344-374: depth_out[H][W] = clamp0(w_stereo * disp16/16 + w_mono * (resize(mono) - min) / (max - min) * 64), float32
+   arithmetic in the reference's order (bit-identical to the NumPy expression); max == min leaves the stereo disparity.
+   mono: f32 [mh][mw] of any size (cv2.resize INTER_LINEAR semantics; same size = no resize).  depth.py uses 0.7 / 0.3.
+   ws: device scratch of v3d_mono_blend_ws_bytes(n) bytes.  Batch: frame f at disp16 + f*W*H, mono + f*mono_stride (floats),
+   depth_out + f*W*H. */
+size_t v3d_mono_blend_ws_bytes(int n);
+int v3d_mono_blend(const int16_t* disp16, int W, int H, const float* mono, int mw, int mh,
+                   float w_stereo, float w_mono, float* depth_out, void* ws, void* stream);
+int v3d_mono_blend_batch(const int16_t* disp16, int n, int W, int H, const float* mono, int mw, int mh, size_t mono_stride,
+                         float w_stereo, float w_mono, float* depth_out, void* ws, void* stream);
 
 /* guided-filter joint upsampling: depth_lo f32 [Hlo][Wlo], guide u8 luma [Hhi][Whi] -> out f32 [Hhi][Whi].
    ws: device scratch of v3d_guided_upscale_ws_bytes(Whi, Hhi) bytes */

@@ -179,6 +179,27 @@ def bilinear_resize(src, Wd, Hd):
     return out
 
 
+def resize_linear_f32(src, Wd, Hd):
+    """cv2.resize(src, (Wd, Hd)) with the default INTER_LINEAR on a float32 image (depth.py:353-354)"""
+    s = np.ascontiguousarray(src, np.float32)
+    out = np.empty((Hd, Wd), np.float32)
+    lib().orc_resize_linear_f32(_p(s, C.c_float), s.shape[1], s.shape[0], Wd, Hd, _p(out, C.c_float))
+    return out
+
+
+def mono_blend(disp16, mono, w_stereo=0.7, w_mono=0.3):
+    """depth.py:344-374: float32 HxW = clamp(w_stereo * disp16/16 + w_mono * minmax64(resize(mono)))"""
+    d = np.ascontiguousarray(disp16, np.int16)
+    m = np.ascontiguousarray(mono, np.float32)
+    out = np.empty(d.shape, np.float32)
+    f = lib().orc_mono_blend
+    f.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float,
+                  C.POINTER(C.c_float)]
+    f.restype = None
+    f(_p(d, C.c_int16), d.shape[1], d.shape[0], _p(m, C.c_float), m.shape[1], m.shape[0], w_stereo, w_mono, _p(out, C.c_float))
+    return out
+
+
 def corr_lookup(fl, fr, flow, groups=4, pattern=0):
     fl = np.ascontiguousarray(fl, np.float32)
     fr = np.ascontiguousarray(fr, np.float32)

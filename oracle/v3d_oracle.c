@@ -459,6 +459,69 @@ void orc_depth_to_u16(const float* d, int n, uint16_t* out)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * depth.py:344-374 -- the "hybrid" blend of the stereo disparity with a monocular depth map.
+ *   :353-354  mono = cv2.resize(mono, (W, H))            (default INTER_LINEAR, float32 image)
+ *   :359-360  mono_n = (mono - min) / (max - min) * 64   (float32 NumPy arithmetic; skipped if max == min)
+ *   :363      combined = 0.7 * disparity + 0.3 * mono_n  (disparity = compute()/16: invalid pixels are -1.0)
+ *   :374      combined[combined <= 0] = 0
+ * cv2.resize INTER_LINEAR on CV_32F [RECALLED, imgproc/resize.cpp]: scale = 1 / ((double)dst / src);
+ * f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s; in x a tap outside the row snaps to the border
+ * pixel with weight 0 (s < 0 -> s = 0, f = 0; s >= w-1 -> s = w-1, f = 0); in y the two row indices are
+ * clamped and the weights kept.  Horizontal pass first (S[s]*(1-f) + S[s+1]*f in float), then vertical
+ * (r0*(1-fy) + r1*fy).  Same-size input is passed through untouched (depth.py:352).
+ * ------------------------------------------------------------------------------------------ */
+void orc_resize_linear_f32(const float* src, int Ws, int Hs, int Wd, int Hd, float* dst)
+{
+    if (Ws == Wd && Hs == Hd) { memcpy(dst, src, sizeof(float) * (size_t)Ws * Hs); return; }
+    const double scx = 1.0 / ((double)Wd / Ws), scy = 1.0 / ((double)Hd / Hs);
+    for (int y = 0; y < Hd; y++) {
+        float fy = (float)((y + 0.5) * scy - 0.5);
+        int sy = (int)floorf(fy); fy -= (float)sy;
+        const int ya = iclamp(sy, 0, Hs - 1), yb = iclamp(sy + 1, 0, Hs - 1);
+        const float b0 = 1.f - fy, b1 = fy;
+        for (int x = 0; x < Wd; x++) {
+            float fx = (float)((x + 0.5) * scx - 0.5);
+            int sx = (int)floorf(fx); fx -= (float)sx;
+            if (sx < 0) { fx = 0.f; sx = 0; }
+            if (sx >= Ws - 1) { fx = 0.f; sx = Ws - 1; }
+            const int sx1 = sx + 1 < Ws ? sx + 1 : sx;
+            const float a0 = 1.f - fx, a1 = fx;
+            volatile float t0 = src[(size_t)ya * Ws + sx] * a0, t1 = src[(size_t)ya * Ws + sx1] * a1;
+            volatile float r0 = t0 + t1;
+            volatile float u0 = src[(size_t)yb * Ws + sx] * a0, u1 = src[(size_t)yb * Ws + sx1] * a1;
+            volatile float r1 = u0 + u1;
+            volatile float v0 = r0 * b0, v1 = r1 * b1;
+            dst[(size_t)y * Wd + x] = v0 + v1;
+        }
+    }
+}
+
+void orc_mono_blend(const int16_t* disp16, int W, int H, const float* mono, int mw, int mh,
+                    float w_stereo, float w_mono, float* out)
+{
+    const size_t n = (size_t)W * H;
+    float* m = (float*)malloc(sizeof(float) * n);
+    orc_resize_linear_f32(mono, mw, mh, W, H, m);
+    float mn = m[0], mx = m[0];
+    for (size_t i = 1; i < n; i++) { if (m[i] < mn) mn = m[i]; if (m[i] > mx) mx = m[i]; }
+    const int flat = !(mx > mn);
+    const float range = mx - mn;
+    for (size_t i = 0; i < n; i++) {
+        volatile float d = (float)disp16[i] / 16.0f;
+        float c = d;
+        if (!flat) {
+            volatile float a = m[i] - mn;
+            volatile float b = a / range;
+            volatile float e = b * 64.0f;
+            volatile float s0 = w_stereo * d, s1 = w_mono * e;
+            c = s0 + s1;
+        }
+        out[i] = c <= 0.f ? 0.f : c;
+    }
+    free(m);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Guided-filter joint upsampling (He, Sun, Tang) -- SURVEY Appendix B.1, float64.
  * ------------------------------------------------------------------------------------------ */
 void orc_bilinear_resize(const float* src, int Ws, int Hs, int Wd, int Hd, double* dst)

@@ -15,6 +15,7 @@
  *   depth.py:274-275, 337-338  cvtColor    -> orc_sbs_to_gray (BGR->gray)
  *   depth.py:315-325, 341  StereoSGBM      -> orc_sgbm_compute
  *   depth.py:341, 374      /16, clamp      -> orc_disp_to_depth
+ *   depth.py:344-374       DPT blend       -> orc_mono_blend (resize INTER_LINEAR + min-max + 0.7/0.3 + clamp)
  *   depth.py:397-406       save_depth_map  -> orc_depth_to_u16
  *   upscale.py:21-73 (re-specified as a guided filter) -> orc_guided_upscale
  *   CREStereo-style group correlation (no reference code) -> orc_corr_lookup
@@ -79,6 +80,11 @@ int orc_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* g
                        int r, double eps, double* out);
 /* the bilinear resample alone (align_corners=False, edge clamp) */
 void orc_bilinear_resize(const float* src, int Ws, int Hs, int Wd, int Hd, double* dst);
+
+/* depth.py:344-374: cv2.resize(mono) INTER_LINEAR float32, min-max to [0, 64], w_stereo*disp + w_mono*mono, clamp <= 0 */
+void orc_resize_linear_f32(const float* src, int Ws, int Hs, int Wd, int Hd, float* dst);
+void orc_mono_blend(const int16_t* disp16, int W, int H, const float* mono, int mw, int mh,
+                    float w_stereo, float w_mono, float* out);
 
 /* CREStereo-style local group correlation, fp32 (SURVEY Appendix B.2 form A).
    fl, fr: [C][h][w] f32; flow: [2][h][w] f32 (x then y); out: [G*9][h][w] f32.

@@ -53,8 +53,29 @@ def main():
     flow = rng.uniform(-2, 2, (2, 6, 20)).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "corr_128x6x20.npz"), fl=fl, fr=fr, flow=flow,
                         out_1x9=O.corr_lookup(fl, fr, flow, 2, 0), out_3x3=O.corr_lookup(fl, fr, flow, 2, 1))
+    blend()
     print("golden vectors written to", HERE)
 
 
+def blend():
+    """depth.py:344-374: disparity (with invalid pixels) blended with a 48x48 'network output' (upscaled) and with a
+    map larger than the frame (downscaled); checked here against the NumPy transcription of depth.py:359-374 on the oracle's resize"""
+    rng = np.random.default_rng(11)
+    L, R = textured_pair(200, 60, 4)
+    d16 = O.sgbm_compute(L, R)
+    mono_small = (rng.random((48, 48)).astype(np.float32) * 20 + 3)
+    mono_big = (rng.random((97, 333)).astype(np.float32) * 5 - 1)
+    out = {}
+    for tag, m in (("small", mono_small), ("big", mono_big)):
+        r = O.resize_linear_f32(m, 200, 60)
+        nb = 0.7 * (d16.astype(np.float32) / 16.0) + 0.3 * ((r - r.min()) / (r.max() - r.min()) * 64)
+        nb[nb <= 0] = 0
+        out[f"mono_{tag}"] = m
+        out[f"resized_{tag}"] = r
+        out[f"blend_{tag}"] = O.mono_blend(d16, m)
+        assert np.array_equal(out[f"blend_{tag}"], nb.astype(np.float32))       # the oracle == depth.py:359-374 written in NumPy float32
+    np.savez_compressed(os.path.join(HERE, "blend_200x60.npz"), disp16=d16, **out)
+
+
 if __name__ == "__main__":
-    main()
+    blend() if sys.argv[1:] == ["blend"] else main()

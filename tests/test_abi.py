@@ -41,6 +41,20 @@ def test_version_and_error_strings():
     assert lib.v3d_sgbm_profile_stage_count() == 13
 
 
+def test_library_reads_no_environment():
+    """tuning goes through v3d_sgbm_set_option / v3d_set_option (declared in the header), never getenv in the C-ABI"""
+    csrc = os.path.join(ROOT, "video-3d-pipeline_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f} reads the environment"
+    assert {"v3d_sgbm_set_option", "v3d_sgbm_get_option", "v3d_set_option"} <= set(_declared_symbols())
+    from video_3d_pipeline import _native
+    lib = _native.lib()
+    assert lib.v3d_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.v3d_last_error()
+    assert lib.v3d_set_option(b"gf_band1", 90) == 0
+    assert lib.v3d_sgbm_set_option(None, b"lockstep", 1) == -1            # null handle is an argument error, not a crash
+
+
 def test_product_does_not_import_the_oracle():
     """the product path must never route through oracle/ (or any CPU fallback)"""
     pkg = os.path.join(ROOT, "video-3d-pipeline_amd")

@@ -49,8 +49,8 @@ def test_rejects_bad_channels(native):
         native.corr_lookup(a, a, torch.zeros((2, 4, 16), device="cuda"), 1, 0)
 
 
-def test_fused_gather_gemm_is_bit_identical(native, monkeypatch):
-    """V3D_CORR_GATHER=1 builds the B operand on the fly (no materialised warp): same bits, measured slower"""
+def test_fused_gather_gemm_is_bit_identical(native):
+    """option corr_gather=1 builds the B operand on the fly (no materialised warp): same bits, measured slower"""
     h, w, G = 10, 40, 2
     g = torch.Generator(device="cpu").manual_seed(3)
     fl = torch.randn((h, w, 64 * G), generator=g).to("cuda", torch.bfloat16)
@@ -58,7 +58,9 @@ def test_fused_gather_gemm_is_bit_identical(native, monkeypatch):
     flow = (torch.rand((2, h, w), generator=g) * 6 - 3).cuda()
     for pat in (0, 1):
         a = native.corr_lookup(fl, fr, flow, G, pat)
-        monkeypatch.setenv("V3D_CORR_GATHER", "1")
-        b = native.corr_lookup(fl, fr, flow, G, pat)
-        monkeypatch.delenv("V3D_CORR_GATHER")
+        native.set_option("corr_gather", 1)
+        try:
+            b = native.corr_lookup(fl, fr, flow, G, pat)
+        finally:
+            native.set_option("corr_gather", 0)
         assert torch.equal(a, b)

@@ -11,8 +11,9 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, tmp, clip):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, tmp, clip, backend="gloo"):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -20,25 +21,55 @@ def _worker(rank, world, port, tmp, clip):
     import torch.distributed as dist
     from video_3d_pipeline import sharding
     from video_3d_pipeline.depth import HybridStereoDepthExtractor
-    from test_host import OracleStereoBackend
+    from test_host import OracleStereoBackend, OracleUpscaleBackend
+    from video_3d_pipeline.upscale import SimpleDepthUpscaler
 
-    sharding.init_process_group("gloo")
+    sharding.init_process_group(backend)
     assert sharding.rank_world() == (rank, world)
+    gpu = backend == "nccl"                                    # RCCL: one GPU per rank, the product's HIP backends
+    dev = torch.device("cuda", torch.cuda.current_device()) if gpu else torch.device("cpu")
+    if gpu:
+        assert torch.cuda.current_device() == rank             # init_process_group selected LOCAL_RANK's GPU
     # 1. guide round broadcast: rank 0 owns the frames, every rank gets its own slot back
     H, W = 6, 10
     rounds = [np.full((H, W), 10 * (r + 1), np.uint8) for r in range(world)] if rank == 0 else None
-    mine = sharding.broadcast_guide_round(rounds, (H, W), torch.device("cpu"))
+    mine = sharding.broadcast_guide_round(rounds, (H, W), dev)
     assert mine is not None and int(mine[0, 0]) == 10 * (rank + 1) and mine.shape == (H, W)
     tail = [np.full((H, W), 7, np.uint8)] + [None] * (world - 1) if rank == 0 else None      # ragged last round
-    mine = sharding.broadcast_guide_round(tail, (H, W), torch.device("cpu"))
+    mine = sharding.broadcast_guide_round(tail, (H, W), dev)
     assert (mine is not None) == (rank == 0)
-    # 2. sharded depth extraction writes disjoint frame sets into one cache dir
+    # 1b. the persistent double-buffered exchange: rounds posted one ahead, ragged tail, one collective per round
+    ex = sharding.GuideRoundExchange((H, W), dev)
+    nfr = 2 * world + 1                                        # two full rounds + one frame
+    def rnd(b):
+        return [np.full((H, W), 1 + b + r, np.uint8) if b + r < nfr else None for r in range(world)] if rank == 0 else None
+    ex.post(rnd(0))
+    for b in range(0, nfr, world):
+        if b + world < nfr:
+            ex.post(rnd(b + world))
+        g = ex.take()
+        i = b + rank
+        assert (g is not None) == (i < nfr)
+        if g is not None:
+            assert g.dtype == torch.uint8 and int(g[0, 0]) == 1 + i and int(g[-1, -1]) == 1 + i
+    # 2. sharded depth extraction writes disjoint frame sets into one cache dir; each rank decodes ONLY its own frames
     ex = HybridStereoDepthExtractor(work_dir=os.path.join(tmp, "w"), cache_dir=os.path.join(tmp, "w"), batch_size=2,
-                                    stereo_only=True, backend=OracleStereoBackend())
+                                    stereo_only=True, backend=None if gpu else OracleStereoBackend())
+    if gpu:
+        assert ex.backend.device.index == rank                 # a bare "cuda" resolved to this rank's GPU
     out = ex.process_video_sbs(clip, max_frames=5, force_reprocess=True)
     dist.barrier()
+    if gpu:
+        assert ex.backend._matcher.device.index == rank and ex.backend._matcher.sync_errors() == 0
+    assert ex.last_decoded_frames == len(range(rank, 5, world))          # ceil(5/2) on rank 0, floor on rank 1
     files = sorted(os.listdir(out))
     assert files == [f"depth_{i:06d}.png" for i in range(5)], files
+    # 3. sharded guided upscale: rank 0 decodes the guide clip, rounds travel through the exchange, ragged last round,
+    #    4 guide frames for 5 depth maps (the last one is beyond the 4K clip: flat guide by design)
+    up = SimpleDepthUpscaler(backend=None if gpu else OracleUpscaleBackend())
+    up.upscale_depth_maps_ffmpeg(str(out), 320, 48, os.path.join(tmp, "up.mp4"), video_4k_path=os.path.join(tmp, "guide.npy"))
+    dist.barrier()
+    assert sorted(os.listdir(os.path.join(tmp, "up_frames"))) == [f"depth4k_{i:06d}.png" for i in range(5)]
     dist.destroy_process_group()
 
 
@@ -50,15 +81,32 @@ def test_round_robin_assignment():
     assert sharding.rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_rccl(tmp_path):
+    """the same scenario on two real GPUs over RCCL (backend nccl) with the product's HIP backends: guide exchange on a
+    side stream, sharded extraction with one matcher per GPU, sharded guided upscale.  Skips on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _two_rank_scenario(tmp_path, "nccl")
+
+
 @pytest.mark.timeout(180)
 def test_two_rank_gloo(tmp_path):
+    _two_rank_scenario(tmp_path, "gloo")
+
+
+def _two_rank_scenario(tmp_path, backend):
     sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
     from video_3d_pipeline import synthetic as syn
     frames = np.stack([syn.sbs_frame(160, 24, i) for i in range(5)])
     clip = str(tmp_path / "clip.npy")
     np.save(clip, frames)
+    guides = np.stack([syn.guide_frame(160, 24, i) for i in range(4)])            # 320 x 48 luma, one frame short of the depth maps
+    np.save(str(tmp_path / "guide.npy"), np.repeat(guides[..., None], 3, axis=3))
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), clip), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), clip, backend), nprocs=2, join=True)
     # sharded result == single-process result
     from oracle import oracle as O
     from video_3d_pipeline.utils import read_png16
@@ -68,3 +116,13 @@ def test_two_rank_gloo(tmp_path):
         l, r = O.sbs_to_gray(frames[i], True)
         want = O.depth_to_u16(O.disp_to_depth(O.sgbm_compute(l, r)))
         assert np.array_equal(read_png16(os.path.join(d, f"depth_{i:06d}.png")), want)
+    # sharded upscale == what one process computes: every frame guided by ITS 4K frame (never a flat guide inside the clip)
+    for i in range(5):
+        lo = read_png16(os.path.join(d, f"depth_{i:06d}.png")).astype(np.float32)
+        g = O.bgr_to_gray(np.repeat(guides[i][..., None], 3, axis=2)) if i < 4 else np.full((48, 320), 128, np.uint8)
+        want = np.clip(np.rint(O.guided_upscale(lo, g, 8, 1e-3)), 0, 65535)
+        got = read_png16(str(tmp_path / "up_frames" / f"depth4k_{i:06d}.png")).astype(np.float64)
+        assert np.abs(got - want).max() <= 1, (i, np.abs(got - want).max())       # rounding of the f32 result at .5
+        if i < 4:                                                                  # ... and a flat guide would be far off
+            flat = O.guided_upscale(lo, np.full((48, 320), 128, np.uint8), 8, 1e-3)
+            assert np.abs(got - flat).max() > 50

@@ -17,14 +17,22 @@ class OracleStereoBackend:
     def split_sbs(self, f, unsqueeze):
         return O.split_sbs(f, unsqueeze)
 
-    def pairs_to_disparity(self, pairs):
-        return [O.disp_to_depth(O.sgbm_compute(O.bgr_to_gray(l), O.bgr_to_gray(r))) for l, r in pairs]
+    def pairs_to_disparity(self, pairs, monos=None):
+        disps = [O.sgbm_compute(O.bgr_to_gray(l), O.bgr_to_gray(r)) for l, r in pairs]
+        if monos is None:
+            return [O.disp_to_depth(d) for d in disps]
+        return [O.mono_blend(d, np.asarray(m, np.float32)) for d, m in zip(disps, monos)]
 
-    def sbs_to_disparity(self, frames, unsqueeze):
+    def sbs_to_disparity(self, frames, unsqueeze, mono_provider=None):
         out = []
         for f in frames:
             l, r = O.sbs_to_gray(f, unsqueeze)
-            out.append(O.disp_to_depth(O.sgbm_compute(l, r)))
+            d = O.sgbm_compute(l, r)
+            if mono_provider is None:
+                out.append(O.disp_to_depth(d))
+            else:
+                left_rgb = O.split_sbs(f, unsqueeze)[0][..., ::-1]
+                out.append(O.mono_blend(d, np.asarray(mono_provider([left_rgb])[0], np.float32)))
         return np.stack(out)
 
     def normalise_u16(self, depth):
@@ -51,7 +59,7 @@ class OracleUpscaleBackend:
             return False
 
     def to_luma(self, frame):
-        return _FakeTensor(frame if frame.ndim == 2 else O.bgr_to_gray(frame))
+        return frame if frame.ndim == 2 else O.bgr_to_gray(frame)
 
     def upscale(self, depth_lo, guide, r, eps):
         if isinstance(guide, _FakeTensor):
@@ -338,3 +346,127 @@ def test_lockstep_timeout_switches_mode_instead_of_failing(capsys):
     assert HipStereoBackend._lockstep_ok(sick) is False and sick.off is True
     assert "over-subscribed" in capsys.readouterr().out
     assert HipStereoBackend._lockstep_ok(sick) is True          # after the switch the handle reports healthy
+
+
+def test_iter_frames_stride_offset(clip):
+    """rank r of a world of w decodes frames r, r + w, ... of the requested range and nothing else"""
+    from video_3d_pipeline.utils import iter_frames
+    path, frames = clip
+    got = list(iter_frames(path, 1, 4, stride=2, offset=1))          # range [1, 5): frames 2 and 4
+    assert len(got) == 2 and np.array_equal(got[0], frames[2]) and np.array_equal(got[1], frames[4])
+    assert [len(list(iter_frames(path, 0, None, stride=3, offset=o))) for o in range(3)] == [2, 2, 1]   # ceil / floor split of 5
+    assert len(list(iter_frames(path, 0, 5))) == 5
+    with pytest.raises(ValueError):
+        list(iter_frames(path, 0, 5, stride=2, offset=2))
+
+
+def _numpy_blend(disp16, mono_resized):
+    """depth.py:341, 359-374 transcribed in NumPy float32 (the resize is the oracle's)"""
+    disparity = disp16.astype(np.float32) / 16.0
+    m = mono_resized
+    if m.max() > m.min():
+        mono_normalized = ((m - m.min()) / (m.max() - m.min()) * 64)
+        combined = 0.7 * disparity + 0.3 * mono_normalized
+    else:
+        combined = disparity
+    combined[combined <= 0] = 0
+    return combined.astype(np.float32)
+
+
+def test_neural_guidance_provider_blend(tmp_path, clip, capsys):
+    """f-4: a monocular-depth provider handed to the extractor is blended in exactly as depth.py:344-374 does"""
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.utils import read_png16
+    path, frames = clip
+    rng = np.random.default_rng(5)
+    seen = []
+
+    def provider(left_rgb_frames):
+        seen.extend(left_rgb_frames)
+        return [rng.random((24, 40)).astype(np.float32) * 9 + 1 for _ in left_rgb_frames]
+
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), batch_size=2,
+                                    backend=OracleStereoBackend(), mono_provider=provider)
+    pairs = [ex.split_sbs_frame(f, True) for f in frames[:2]]
+    rng = np.random.default_rng(5)
+    out = ex.process_frame_batch(pairs)
+    assert not ex.stereo_only and "supplied monocular depth provider" in capsys.readouterr().out
+    assert len(seen) == 2 and np.array_equal(seen[0], pairs[0][0][..., ::-1])          # the left view, as RGB (depth.py:274)
+    rng = np.random.default_rng(5)
+    for (l, r), got in zip(pairs, out):
+        mono = rng.random((24, 40)).astype(np.float32) * 9 + 1
+        d16 = O.sgbm_compute(O.bgr_to_gray(l), O.bgr_to_gray(r))
+        want = _numpy_blend(d16, O.resize_linear_f32(mono, d16.shape[1], d16.shape[0]))
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        assert (got[:, :64] > 0).any()                  # 0.7 * (-1) + 0.3 * mono: invalid columns are filled by the mono term
+    # stereo_only / --no-neural wins over a provider (depth.py:344: `not self.stereo_only`)
+    ex2 = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w2"), cache_dir=str(tmp_path / "w2"), stereo_only=True,
+                                     backend=OracleStereoBackend(), mono_provider=provider)
+    plain = ex2.process_frame_batch(pairs[:1])[0]
+    assert np.array_equal(plain, O.disp_to_depth(O.sgbm_compute(O.bgr_to_gray(pairs[0][0]), O.bgr_to_gray(pairs[0][1]))))
+    # a failing provider degrades to stereo-only for that batch with the reference's warning (depth.py:367-369)
+    ex3 = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w3"), cache_dir=str(tmp_path / "w3"),
+                                     backend=OracleStereoBackend(), mono_provider=lambda fr: 1 / 0)
+    assert np.array_equal(ex3.process_frame_batch(pairs[:1])[0], plain)
+    assert "Neural guidance failed, using stereo only" in capsys.readouterr().out
+    # the streaming path blends too
+    outdir = ex.process_video_sbs(path, max_frames=2)
+    a = read_png16(outdir / "depth_000000.png")
+    assert a.shape == (48, 192) and a.max() == 65535
+
+
+def test_load_model_local_directory_and_fallback(tmp_path, capsys):
+    """f-4 hook: DPT weights in a LOCAL directory load (nothing is downloaded); a bare model name that is not in the
+    HF cache falls back to stereo-only with the reference's warning (depth.py:107-114)"""
+    pytest.importorskip("transformers")
+    import torch
+    from transformers import DPTConfig, DPTForDepthEstimation, DPTImageProcessor
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    cfg = DPTConfig(hidden_size=32, num_hidden_layers=4, num_attention_heads=2, intermediate_size=64, image_size=64, patch_size=16,
+                    backbone_out_indices=[0, 1, 2, 3], neck_hidden_sizes=[16, 32, 64, 64], fusion_hidden_size=32,
+                    reassemble_factors=[4, 2, 1, 0.5], is_hybrid=False)
+    torch.manual_seed(0)
+    d = tmp_path / "tiny_dpt"
+    DPTForDepthEstimation(cfg).save_pretrained(d)
+    DPTImageProcessor(size={"height": 64, "width": 64}).save_pretrained(d)
+    ex = HybridStereoDepthExtractor(model_checkpoint=str(d), work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"),
+                                    device="cpu", backend=OracleStereoBackend())
+    ex.load_model()
+    assert ex.model_loaded and not ex.stereo_only and ex.model is not None and "Model loaded successfully" in capsys.readouterr().out
+    rng = np.random.default_rng(1)
+    pair = (rng.integers(0, 255, (40, 160, 3), dtype=np.uint8),) * 2
+    got = ex.process_frame_batch([pair])[0]
+    mono = ex._dpt_provider([np.ascontiguousarray(pair[0][..., ::-1])])[0].numpy()
+    d16 = O.sgbm_compute(O.bgr_to_gray(pair[0]), O.bgr_to_gray(pair[1]))
+    assert mono.shape == (64, 64) and np.array_equal(got, O.mono_blend(d16, mono))
+    ex2 = HybridStereoDepthExtractor(model_checkpoint="Intel/dpt-large", work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"),
+                                     device="cpu", backend=OracleStereoBackend())
+    ex2.load_model()
+    assert ex2.stereo_only and "falling back to stereo-only mode" in capsys.readouterr().out
+
+
+def test_world_without_process_group_fails_loudly(tmp_path, clip, monkeypatch):
+    """WORLD_SIZE > 1 from the environment but no process group must never shard silently"""
+    import torch.distributed as dist
+    from video_3d_pipeline import sharding
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.upscale import SimpleDepthUpscaler
+    if dist.is_initialized():
+        pytest.skip("a process group is live")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(RuntimeError, match="not initialised"):
+        sharding.barrier()
+    with pytest.raises(RuntimeError, match="not initialised"):
+        sharding.broadcast_guide_round(None, (4, 4), "cpu")
+    path, _ = clip
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), stereo_only=True,
+                                    backend=OracleStereoBackend())
+    with pytest.raises(RuntimeError, match="not initialised"):
+        ex.process_video_sbs(path, max_frames=2)
+    (tmp_path / "d").mkdir()
+    from video_3d_pipeline.utils import write_png16
+    write_png16(tmp_path / "d" / "depth_000000.png", np.zeros((4, 4), np.uint16))
+    up = SimpleDepthUpscaler(backend=OracleUpscaleBackend())
+    with pytest.raises(RuntimeError, match="not initialised"):
+        up.upscale_depth_maps_ffmpeg(str(tmp_path / "d"), 8, 8, str(tmp_path / "o.mp4"), video_4k_path=path)

@@ -93,4 +93,61 @@ def test_bench_line_contract(native):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert d["value"] > 0 and d["lockstep_timeouts"] == 0
+    assert d["value"] > 0 and d["lockstep_timeouts"] == 0 and d["lockstep_recomputed"] is False
+    assert d["parity_check"] is None                                   # --no-cpu-baseline: no oracle leg, no stamp
+    assert d["config"]["distinct_frames_per_gpu"] == 4
+    e = d["e2e"]
+    assert e["value"] > 0 and e["unit"] == "frames/s" and e["batch4"]["latency_p50_ms_per_batch"] > 0 and e["lockstep_timeouts"] == 0
+    x = d["extra"]
+    assert x["sgbm_only"]["value"] > 0 and x["hh"]["value"] > 0 and x["corr"]["value"] > 0 and x["hh"]["lockstep_timeouts"] == 0
+
+
+def test_config0_64_frames_960x540_on_the_hip_backend(native, oracle, tmp_path):
+    """BASELINE.json configs[0]: a 64-frame 960x540 synthetic SBS clip through `process_video_sbs` -- here on the HIP
+    backend (batch loop of depth.py:448-470 at the reference's batch size 8); every PNG equals the oracle's"""
+    from concurrent.futures import ThreadPoolExecutor
+    from video_3d_pipeline import synthetic as syn
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.utils import read_png16
+    base = [syn.sbs_frame(960, 540, i) for i in range(4)]
+    frames = np.stack([base[i % 4] for i in range(64)])
+    clip = tmp_path / "clip960.npy"
+    np.save(clip, frames)
+    ex = HybridStereoDepthExtractor(work_dir=str(tmp_path / "w"), cache_dir=str(tmp_path / "w"), batch_size=8, stereo_only=True)
+    out = ex.process_video_sbs(str(clip))
+    assert sorted(os.listdir(out)) == [f"depth_{i:06d}.png" for i in range(64)] and ex.last_decoded_frames == 64
+
+    def want(i):
+        l, r = oracle.sbs_to_gray(base[i], True)
+        return oracle.depth_to_u16(oracle.disp_to_depth(oracle.sgbm_compute(l, r)))
+    with ThreadPoolExecutor(4) as pool:
+        wants = list(pool.map(want, range(4)))
+    for i in range(64):
+        a = read_png16(out / f"depth_{i:06d}.png")
+        assert a.shape == (540, 960) and np.array_equal(a, wants[i % 4]), i
+
+
+def test_backend_follows_the_current_device(native):
+    """a bare "cuda" resolves to the CURRENT device for tensors, workspace and kernels alike"""
+    import torch
+    from video_3d_pipeline.depth import HipStereoBackend
+    from video_3d_pipeline.upscale import HipUpscaleBackend
+    cur = torch.cuda.current_device()
+    assert native.resolve_device("cuda").index == cur and native.resolve_device(None).index == cur
+    assert native.resolve_device("cuda:0").index == 0 and native.resolve_device(0).index == 0
+    with pytest.raises(native.NativeError):
+        native.resolve_device("cpu")
+    if torch.cuda.device_count() < 2:
+        assert HipStereoBackend("cuda").device.index == cur and HipUpscaleBackend("cuda").device.index == cur
+        return
+    from conftest import textured_pair
+    torch.cuda.set_device(1)
+    try:
+        b = HipStereoBackend("cuda")
+        assert b.device.index == 1
+        L, R = textured_pair(200, 40, 1)
+        bgr = lambda g: np.repeat(g[..., None], 3, axis=2)
+        out = b.pairs_to_disparity([(bgr(L), bgr(R))])
+        assert b._matcher.device.index == 1 and out[0].shape == (40, 200)
+    finally:
+        torch.cuda.set_device(cur)

@@ -196,3 +196,37 @@ def test_golden_vectors_pin_the_oracle(oracle):
     assert np.allclose(oracle.guided_upscale(z["depth"], z["guide"], 8, 1e-3), z["q"], rtol=1e-12, atol=1e-12)
     z = np.load(os.path.join(GOLD, "corr_128x6x20.npz"))
     assert np.allclose(oracle.corr_lookup(z["fl"], z["fr"], z["flow"], 2, 0), z["out_1x9"], rtol=1e-6, atol=1e-6)
+    z = np.load(os.path.join(GOLD, "blend_200x60.npz"))
+    for tag in ("small", "big"):
+        assert np.array_equal(oracle.resize_linear_f32(z[f"mono_{tag}"], 200, 60), z[f"resized_{tag}"])
+        assert np.array_equal(oracle.mono_blend(z["disp16"], z[f"mono_{tag}"]), z[f"blend_{tag}"])
+        r = z[f"resized_{tag}"]
+        nb = 0.7 * (z["disp16"].astype(np.float32) / 16.0) + 0.3 * ((r - r.min()) / (r.max() - r.min()) * 64)
+        nb[nb <= 0] = 0
+        assert np.array_equal(z[f"blend_{tag}"], nb.astype(np.float32))          # == depth.py:359-374 written in NumPy float32
+
+
+def test_mono_blend_known_answers(oracle):
+    """depth.py:344-374 restatement: resize properties, the max == min bypass, the clamp, the weights"""
+    rng = np.random.default_rng(2)
+    # resize: constants stay constant, same size is the identity, a horizontal ramp stays linear in the interior,
+    # exact 2x decimation is the 2x2 mean (linear taps at phase 0.5)
+    assert np.all(oracle.resize_linear_f32(np.full((7, 9), 2.5, np.float32), 31, 17) == 2.5)
+    m = rng.random((12, 16)).astype(np.float32)
+    assert np.array_equal(oracle.resize_linear_f32(m, 16, 12), m)
+    ramp = np.tile(np.arange(10, dtype=np.float32), (4, 1))
+    up = oracle.resize_linear_f32(ramp, 40, 4)
+    assert np.allclose(up[:, 2:-2], ((np.arange(40) + 0.5) / 4 - 0.5)[None, 2:-2], atol=1e-5) and up[0, 0] == 0 and up[0, -1] == 9
+    half = oracle.resize_linear_f32(m, 8, 6)
+    assert np.allclose(half, m.reshape(6, 2, 8, 2).mean(axis=(1, 3)), atol=1e-6)
+    # blend
+    d16 = (rng.integers(-1, 64, (12, 16)) * 16).astype(np.int16)
+    flat = oracle.mono_blend(d16, np.full((5, 5), 3.0, np.float32))
+    assert np.array_equal(flat, oracle.disp_to_depth(d16))                      # max == min: stereo only (depth.py:359, 365)
+    b = oracle.mono_blend(d16, m)
+    lo, hi = m.min(), m.max()
+    want = 0.7 * (d16.astype(np.float32) / 16.0) + 0.3 * ((m - lo) / (hi - lo) * 64)
+    want[want <= 0] = 0
+    assert np.array_equal(b, want.astype(np.float32)) and b.min() >= 0 and b.max() <= 0.7 * 63 + 0.3 * 64 + 1e-4
+    inv = d16 == -16
+    assert np.array_equal(b[inv] > 0, (0.3 * ((m - lo) / (hi - lo) * 64) > 0.7)[inv])   # invalid (-1.0) pixels: the mono term decides

@@ -7,7 +7,7 @@ from conftest import mismatch_report, textured_pair
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [(160, 96), (320, 180), (203, 77), (480, 270)]
+SIZES = [(160, 96), (320, 180), (203, 77), (480, 270), (960, 540)]      # (960, 540) = BASELINE configs[0] geometry
 
 
 def _dev(native, a):
@@ -116,15 +116,13 @@ def test_batch_equals_single(native, matcher):
         assert not mismatch_report(both[i], one, f"batch[{i}]"), mismatch_report(both[i], one, f"batch[{i}]")
 
 
-def test_chain_lane_mappings_agree(native, oracle, monkeypatch):
+def test_chain_lane_mappings_agree(native, oracle):
     """both k_chain lane mappings (8 and 4 disparities per lane) give the oracle's bits"""
     W, H = 230, 90
     L, R = textured_pair(W, H, seed=31)
     want = oracle.sgbm_compute(L, R)
-    monkeypatch.setenv("V3D_VDD", "0")                      # the per-direction k_chain launches
-    for dpl in ("8", "4"):
-        monkeypatch.setenv("V3D_CHAIN_DPL", dpl)
-        m = native.StereoSGBM(max_width=W, max_height=H)
+    for dpl in (8, 4):
+        m = native.StereoSGBM(max_width=W, max_height=H, options={"lockstep": 0, "chain_dpl": dpl})   # the per-direction k_chain launches
         got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
         m.close()
         assert not mismatch_report(got, want, f"dpl={dpl}"), mismatch_report(got, want, f"dpl={dpl}")
@@ -187,15 +185,13 @@ def test_full_size_1080p_properties(native, oracle, matcher):
     assert not mismatch_report(d, want, "1080p disp16"), mismatch_report(d, want, "1080p disp16")
 
 
-@pytest.mark.parametrize("dpl", ["4", "8"])
+@pytest.mark.parametrize("dpl", [4, 8])
 @pytest.mark.parametrize("W,H,n", [(160, 96, 1), (203, 77, 2), (320, 180, 3), (64 + 128, 40, 1), (64 + 129, 33, 2), (64 + 256, 21, 1)])
-def test_lockstep_top_down_kernel(native, oracle, monkeypatch, W, H, n, dpl):
-    """V3D_VDD=1: r1 + r2 + r3 in one lock-step pass (k_vdd) instead of three k_chain launches.
+def test_lockstep_top_down_kernel(native, oracle, W, H, n, dpl):
+    """r1 + r2 + r3 in one lock-step pass (k_vdd) instead of three k_chain launches, both strip mappings.
     Covers strips that end mid-image, exact multiples of the strip width, multi-frame launches."""
-    monkeypatch.setenv("V3D_VDD", "1")
-    monkeypatch.setenv("V3D_VDD_DPL", dpl)
     pairs = [textured_pair(W, H, seed=50 + i) for i in range(n)]
-    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n)
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n, options={"lockstep": 1, "vdd_dpl": dpl})
     Ls = _dev(native, np.stack([p[0] for p in pairs]))
     Rs = _dev(native, np.stack([p[1] for p in pairs]))
     for rep in range(2):                                    # second call: fresh sequence tag over stale granules
@@ -221,16 +217,14 @@ PARAM_SETS = [
 
 
 @pytest.mark.parametrize("kw", PARAM_SETS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
-@pytest.mark.parametrize("vdd", ["1", "0"])
-def test_parameter_sweep(native, oracle, monkeypatch, kw, vdd):
+@pytest.mark.parametrize("vdd", [1, 0])
+def test_parameter_sweep(native, oracle, kw, vdd):
     """every StereoSGBM_create keyword the build accepts, away from depth.py's values, through both the
     lock-step (k_vdd + k_hfused) and the per-direction (k_chain) code paths"""
-    monkeypatch.setenv("V3D_VDD", vdd)
-    monkeypatch.setenv("V3D_HFUSED", vdd)
     W, H = 250, 64
     L, R = textured_pair(W, H, seed=sum(kw.values()) + 3)
     want = oracle.sgbm_compute(L, R, oracle.default_params(**kw))
-    m = native.StereoSGBM(max_width=W, max_height=H, **kw)
+    m = native.StereoSGBM(max_width=W, max_height=H, options={"lockstep": vdd, "hfused": vdd}, **kw)
     got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
     assert m.sync_errors() == 0
     m.close()
@@ -307,3 +301,85 @@ def test_lockstep_runtime_switch(native, oracle):
     assert m.sync_errors() == 0
     m.close()
     assert np.array_equal(a, want) and np.array_equal(b, want) and np.array_equal(c, want)
+
+
+def test_benchmarked_configuration_bit_exact(native, oracle):
+    """bench.py's own configuration: 1920x1080, 30 frames per call on a max_batch=30 handle.  That is the path the
+    headline number runs and nothing smaller reaches it: k_vdd<8> (128-column strips, the last one ragged: 1856 = 14 x 128
+    + 64), 450 co-resident lock-step workgroups, the XCD tile order of k_cost over 30 frames, batch-wide CCL.
+    Five distinct frames, cycled; EVERY frame of the batch must equal the oracle's bits."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from video_3d_pipeline import synthetic as syn
+    W, H, n, nd = 1920, 1080, 30, 5
+    pairs = [syn.gray_pair(W, H, 100 + i) for i in range(nd)]
+    with ThreadPoolExecutor(nd) as ex:                       # ctypes releases the GIL inside liboracle.so
+        want = list(ex.map(lambda p: oracle.sgbm_compute(*p), pairs))
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n)
+    assert n > m.get_option("vdd_frames_per_launch_dpl4"), "batch must be large enough to select the 8-disparities-per-lane strips"
+    assert m.get_option("vdd_frames_per_launch_dpl8") >= 1 and m.get_option("lockstep") == 1
+    Ls = _dev(native, np.stack([pairs[i % nd][0] for i in range(n)]))
+    Rs = _dev(native, np.stack([pairs[i % nd][1] for i in range(n)]))
+    wd = [_dev(native, w) for w in want]
+    for rep in range(2):
+        got = m.compute(Ls, Rs)
+        assert m.sync_errors() == 0
+        for i in range(n):
+            if not torch.equal(got[i], wd[i % nd]):
+                g = got[i].cpu().numpy()
+                raise AssertionError(mismatch_report(g, want[i % nd], f"batch-30 frame {i} rep {rep}"))
+    # batch 16 on the same handle: still above the 4-per-lane bound, one launch of 16 x 15 strips
+    got = m.compute(Ls[:16].contiguous(), Rs[:16].contiguous())
+    assert m.sync_errors() == 0
+    for i in range(16):
+        assert torch.equal(got[i], wd[i % nd]), f"batch-16 frame {i}"
+    m.close()
+
+
+def test_lockstep_timeout_is_never_silent(native, oracle):
+    """a timed-out lock-step pass must not hand out disparities.  vdd_spin_limit = -1 makes every workgroup
+    report a time-out: the call's output is invalidated on the device, the next call raises, set_lockstep() recovers."""
+    W, H, n = 64 + 256, 120, 2
+    pairs = [textured_pair(W, H, seed=90 + i) for i in range(n)]
+    want = [oracle.sgbm_compute(*p) for p in pairs]
+    Ls = _dev(native, np.stack([p[0] for p in pairs])); Rs = _dev(native, np.stack([p[1] for p in pairs]))
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n, options={"vdd_spin_limit": -1})
+    got = m.compute(Ls, Rs).cpu().numpy()
+    assert m.poll_errors() > 0 and m.sync_errors() > 0
+    assert (got == -16).all(), "a timed-out pass must leave no disparity behind"
+    with pytest.raises(native.LockstepTimeout):
+        m.compute(Ls, Rs)
+    m.set_lockstep(False)                                    # what depth.py does: per-direction launches, same bits
+    got = m.compute(Ls, Rs).cpu().numpy()
+    assert m.sync_errors() == 0 and m.get_option("lockstep") == 0
+    for i in range(n):
+        assert not mismatch_report(got[i], want[i], f"fallback frame {i}")
+    m.set_option("vdd_spin_limit", 0)
+    m.set_lockstep(True)
+    got = m.compute(Ls, Rs).cpu().numpy()
+    assert m.sync_errors() == 0 and m.poll_errors() == 0
+    for i in range(n):
+        assert not mismatch_report(got[i], want[i], f"lock-step frame {i}")
+    with pytest.raises(native.NativeError):
+        m.set_option("no_such_option", 1)
+    m.close()
+
+
+def test_reserved_cus_shrink_the_lockstep_launch(native, oracle):
+    """reserve_cus (CUs a concurrent collective keeps busy) lowers the frames per lock-step launch; a batch then takes
+    several launches and still gives the oracle's bits"""
+    W, H, n = 64 + 300, 60, 3
+    pairs = [textured_pair(W, H, seed=120 + i) for i in range(n)]
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n)
+    full = m.get_option("vdd_frames_per_launch_dpl4")
+    ncu_res = 0
+    while m.get_option("vdd_frames_per_launch_dpl4") > 1 and ncu_res < 250:     # shrink until one frame per launch
+        ncu_res += 2
+        m.set_option("reserve_cus", ncu_res)
+    assert 1 <= m.get_option("vdd_frames_per_launch_dpl4") < full
+    m.set_option("vdd_dpl", 4)
+    got = m.compute(_dev(native, np.stack([p[0] for p in pairs])), _dev(native, np.stack([p[1] for p in pairs]))).cpu().numpy()
+    assert m.sync_errors() == 0
+    m.close()
+    for i in range(n):
+        assert not mismatch_report(got[i], oracle.sgbm_compute(*pairs[i]), f"frame {i}")

@@ -15,5 +15,5 @@ W, H, B = 1920, 1080, int(os.environ.get("QB_BATCH", "30"))
 depth = N.to_device(np.stack([syn.gt_disparity(W, H).astype(np.float32)] * B)); guide = N.to_device(np.stack([syn.guide_frame(W, H, 0)] * B))
 out = torch.empty((B, 2*H, 2*W), dtype=torch.float32, device="cuda")
 for b1, b2 in ((40, 270), (60, 270), (90, 270), (120, 270), (180, 270), (60, 180), (60, 540), (90, 135), (90, 360)):
-    os.environ["V3D_GF_BAND1"] = str(b1); os.environ["V3D_GF_BAND2"] = str(b2)
+    N.set_option("gf_band1", b1); N.set_option("gf_band2", b2)
     t = timeit(lambda: N.guided_upscale_batch(depth, guide, 8, 1e-3, out)); print(f"bands {b1}/{b2}: {t:.3f} ms / {B} frames = {t / B:.4f} ms/frame")

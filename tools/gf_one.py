@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
 import numpy as np, torch
 from video_3d_pipeline import _native as N, synthetic as syn
+import envopts; envopts.apply_lib_options(N)
 W, H, B = 1920, 1080, int(os.environ.get("QB_BATCH", "30"))
 depth = N.to_device(np.stack([syn.gt_disparity(W, H).astype(np.float32)] * B)); guide = N.to_device(np.stack([syn.guide_frame(W, H, 0)] * B))
 out = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device="cuda")

@@ -9,9 +9,8 @@ L, R = syn.gray_pair(W, H, 0)
 Ld = N.to_device(np.stack([L] * B)); Rd = N.to_device(np.stack([R] * B))
 out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
 ref = None
-for vdd in ("1", "0"):
-    os.environ["V3D_VDD"] = vdd
-    m = N.StereoSGBM(W, H, B, mode=1)
+for vdd in (1, 0):
+    m = N.StereoSGBM(W, H, B, mode=1, options={"lockstep": vdd})
     for _ in range(2): m.compute(Ld, Rd, out)
     torch.cuda.synchronize(); m.profile(True)
     for _ in range(5): m.compute(Ld, Rd, out)

@@ -1,9 +1,10 @@
-"""A/B of SGBM build variants in ONE process (env switches are read at v3d_sgbm_create)."""
+"""A/B of SGBM variants in ONE process: VARIANTS="HFUSED=1,DPL=8;..." -> v3d_sgbm_set_option (tools/envopts.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
 import numpy as np, torch
 from video_3d_pipeline import _native as N, synthetic as syn
+import envopts
 W, H = int(os.environ.get("QB_W", "1920")), int(os.environ.get("QB_H", "1080"))
 B = int(os.environ.get("QB_BATCH", "8"))
 L, R = syn.gray_pair(W, H, 0)
@@ -14,9 +15,10 @@ ref = None
 ms = {}
 for rnd in range(int(os.environ.get("ROUNDS", "2"))):
     for v in variants:
+        env = dict(os.environ)
         for kv in v.split(","):
-            k, val = kv.split("="); os.environ["V3D_" + ("CHAIN_DPL" if k == "DPL" else k)] = val
-        m = N.StereoSGBM(W, H, B)
+            k, val = kv.split("="); env["V3D_" + ("CHAIN_DPL" if k == "DPL" else k)] = val
+        m = N.StereoSGBM(W, H, B, options=envopts.sgbm_options(env))
         for _ in range(2): m.compute(Ld, Rd, out)
         torch.cuda.synchronize()
         m.profile(True)

@@ -1,6 +1,5 @@
 """does running two half-batches on two streams overlap the memory-bound and the instruction-bound kernels?"""
 import os, sys
-os.environ["V3D_VDD_DPL"] = "8"          # 2 x 225 lock-step workgroups stay co-resident
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
 import numpy as np, torch
@@ -17,11 +16,11 @@ def timeit(fn, n=8, warm=2):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-m = N.StereoSGBM(W, H, B)
+m = N.StereoSGBM(W, H, B, options={"vdd_dpl": 8})          # 2 x 225 lock-step workgroups stay co-resident
 t1 = timeit(lambda: m.compute(Ld, Rd, out)); print(f"one stream, batch 30: {t1:.3f} ms  ({t1 / B:.4f} ms/frame)")
 ref = out.clone(); m.close()
 h = B // 2
-ms = [N.StereoSGBM(W, H, h) for _ in range(2)]
+ms = [N.StereoSGBM(W, H, h, options={"vdd_dpl": 8}) for _ in range(2)]
 ss = [torch.cuda.Stream() for _ in range(2)]
 def two():
     cur = torch.cuda.current_stream()

@@ -12,6 +12,15 @@
 
 void v3d_set_error(const char* fmt, ...);
 
+// library-wide tuning switches (v3d_set_option); the library reads no environment variables
+struct v3d_lib_options {
+    int gf_band1, gf_band2;   // rows per workgroup of the guided sweeps (measured best on 30 x 4K frames)
+    int gf_tiled;             // 1: force the LDS-tiled guided kernel for every radius
+    int gf_fused;             // 1: single-launch guided filter (a/b rows kept in an LDS ring), 0: two sweeps through HBM
+    int corr_gather;          // 1: fused gather-GEMM correlation (bit-identical, VALU-bound, slower)
+};
+extern v3d_lib_options g_v3d_opt;
+
 #define V3D_HIP_CHECK(expr)                                                              \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \

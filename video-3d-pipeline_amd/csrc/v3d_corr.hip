@@ -219,7 +219,7 @@ extern "C" int v3d_corr_lookup(const uint16_t* fl, const uint16_t* fr, const flo
     const int nwaves = ((w + 15) / 16) * h;
     // measured (270x480x256, MI355X): warp + GEMM 67 us (1x9) / 91 us (3x3); fused gather-GEMM 76 / 198 us -- the per-use
     // bilinear blend makes the fused form VALU-bound, so the materialised warp stays the default
-    if (getenv("V3D_CORR_GATHER")) {
+    if (g_v3d_opt.corr_gather) {
         if (pattern == 0) hipLaunchKernelGGL(k_corr_gather<0>, dim3(v3d_cdiv(nwaves, 4)), dim3(256), 0, st, fl, fr, flow, C, h, w, G, out);
         else hipLaunchKernelGGL(k_corr_gather<1>, dim3(v3d_cdiv(nwaves, 4)), dim3(256), 0, st, fl, fr, flow, C, h, w, G, out);
         V3D_LAUNCH_CHECK();

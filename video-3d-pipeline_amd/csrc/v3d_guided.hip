@@ -366,9 +366,7 @@ static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* g
 {
     // band heights (measured sweep, 30 x 4K frames): each band pays 2r warm-up rows; sweep 1 is VALU-bound, sweep 2
     // is bound by its re-reads of the f64 a/b planes
-    const char* e1 = getenv("V3D_GF_BAND1");
-    const char* e2 = getenv("V3D_GF_BAND2");
-    const int band1 = e1 ? atoi(e1) : 90, band2 = e2 ? atoi(e2) : 270;
+    const int band1 = g_v3d_opt.gf_band1, band2 = g_v3d_opt.gf_band2;
     const dim3 grid1(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band1), n), grid2(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band2), n);
     hipLaunchKernelGGL((k_gfm<1, RR>), grid1, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band1, A, B, out, depth_stride, guide_stride);
     hipLaunchKernelGGL((k_gfm<2, RR>), grid2, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band2, A, B, out, depth_stride, guide_stride);
@@ -400,7 +398,7 @@ extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo,
     hipStream_t st = (hipStream_t)stream;
     double* A = reinterpret_cast<double*>(ws);
     double* B = A + (size_t)W * H;
-    if (!getenv("V3D_GF_TILED") && (r == 4 || r == 8)) {     // larger rings spill: r = 16 takes the tiled kernel
+    if (!g_v3d_opt.gf_tiled && (r == 4 || r == 8)) {     // larger rings spill: r = 16 takes the tiled kernel
         if (r == 4) launch_gfm<4>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
         else launch_gfm<8>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
         V3D_LAUNCH_CHECK();

@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
         uint8_t* sR = sRow[y & 1];                                  // double-buffered: one barrier per row
         const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;     // this eye's half row: hw BGR pixels
         int soff = 0;                                               // byte offset of pixel s0 inside sR
-        if (interior) {
+        // a half row that starts at the row's first byte on an address that is not dword-aligned would be read from up
+        // to 3 bytes BEFORE the row (before the caller's buffer for row 0 of frame 0): such rows take the byte path.
+        // (uniform per workgroup and row; never true for pitches and bases that are multiples of 4, e.g. torch tensors)
+        const bool head_unaligned = (eye | s0) == 0 && (reinterpret_cast<uintptr_t>(row) & 3) != 0;
+        if (interior && !head_unaligned) {
             // aligned dword loads of the span; the <= 3 bytes of over-read stay inside this image row
             // (edge blocks take the clamped byte path)
             const uintptr_t a = reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3);

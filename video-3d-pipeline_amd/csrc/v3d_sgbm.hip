@@ -13,6 +13,7 @@
 //   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
 #include "v3d_common.h"
 #include <vector>
+#include <string.h>
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
@@ -669,13 +670,18 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 // ------------------------------------------------------------------------------------------------
 #define VDD_RING 4
 #define VDD_GRAN 34                      // granules per edge per row: 32 data dwords + delta (+1 pad)
-#define VDD_SPIN_LIMIT (1 << 20)
+// poll budget of one lane over the whole pass (every poll round is one L2 round trip, ~1 us): a healthy pass spends one
+// to three rounds per row, so 64 per row + slack is two orders of magnitude of headroom and still bounds a pass whose
+// neighbours never become resident to ~0.1 s at 1080 rows (it was 2^20 rounds, i.e. seconds)
+#define VDD_SPIN_PER_ROW 64
+#define VDD_SPIN_SLACK 4096
 
 struct VddArgs {
     const int16_t* C; int16_t* S;
     int W1, H, nframes, nstrips;
     int P1, P2;
     uint32_t seq;
+    int spin_limit;                     // poll rounds a lane may spend waiting over the whole pass
     unsigned long long* gran;           // [frame][strip][2 dirs][VDD_RING][VDD_GRAN]
     int* err;
     int xcd;                            // 1: XCD-contiguous strip order.  Measured slower (3.48 -> 4.58 ms per 30 frames): off
@@ -747,8 +753,8 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     const bool edge_l = has_left && wv == 0;                      // wave-uniform: this wave talks to the left strip
     const bool edge_r = has_right && wv == 15;                     //               ... to the right strip
     const bool lane_l = lane < LPP, lane_r = lane >= 64 - LPP;     // lanes of the strip's first / last pixel
-    int budget = VDD_SPIN_LIMIT;
-    bool failed = false;
+    int budget = a.spin_limit;
+    bool failed = a.spin_limit < 0 && tid == 0;                    // spin_limit -1: test hook, every workgroup reports a time-out
 
     // row -1: every path starts from the out-of-image state (L = 0, delta = P2)
     {
@@ -854,6 +860,20 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     };
     if (edge_l || edge_r) rows(std::true_type{}); else rows(std::false_type{});
     if (failed) atomicAdd(a.err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lock-step guard: the last launch of a compute call that used k_vdd.  If any strip of this handle has timed out
+// since the counter was last cleared, the caller must never consume the disparities: every output pixel becomes
+// INVALID and a flag lands in host-visible memory (the next API call on the handle then returns V3D_ERR_LOCKSTEP).
+// Healthy path: one dword load per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vdd_guard(const int* __restrict__ err, volatile int* err_host, int16_t* __restrict__ out, size_t n)
+{
+    const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *err_host = e; __threadfence_system(); }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (int16_t)V3D_INVALID16;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1124,6 +1144,12 @@ struct v3d_sgbm {
     int cost_band;                              // rows per k_cost workgroup
     int vdd_xcd, cost_xcd, hf_xcd;
     int vdd_mf4, vdd_mf8;                       // co-residency bound (frames per launch) of each mapping
+    int vdd_occ4, vdd_occ8, ncu;                // occupancy query results the bounds are derived from
+    int reserve_cus;                            // CUs left to other streams' kernels (e.g. an RCCL collective) when sizing a lock-step launch
+    int vdd_spin_limit;                         // 0 = derive from the row count
+    int* err_host;                              // pinned, device-visible: lock-step time-outs seen by k_vdd_guard
+    hipEvent_t vdd_done_ev;                     // recorded behind the last lock-step launch of a compute call
+    bool vdd_ev_recorded;
     bool hfused;
     int32_t* labels;
     size_t bytes;
@@ -1160,6 +1186,64 @@ template <typename T> static int ws_alloc(T** p, size_t n, size_t* total)
     return V3D_OK;
 }
 
+// frames one lock-step launch may hold: workgroup slots the occupancy query reports, minus the CUs the host says
+// other streams keep busy (two slots each), with a 10 % margin, over the strips of one frame
+static void vdd_size_launches(v3d_sgbm* h)
+{
+    const int cus = h->ncu - h->reserve_cus > 0 ? h->ncu - h->reserve_cus : 0;
+    h->vdd_mf4 = (h->vdd_occ4 * cus * 9 / 10) / v3d_cdiv(h->maxW - V3D_D, 64);
+    h->vdd_mf8 = (h->vdd_occ8 * cus * 9 / 10) / v3d_cdiv(h->maxW - V3D_D, 128);
+}
+static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_mf4 >= 1 && h->vdd_mf8 >= 1; }
+
+// Tuning switches of a handle (A/B work, tests, tools): the defaults are the measured best, nothing here changes results.
+//   "lockstep"       1/0  top-down paths in one co-resident lock-step pass (k_vdd) / one launch per direction (k_chain)
+//   "hfused"         1/0  both horizontal paths + WTA in one launch (k_hfused) / two k_chain launches
+//   "chain_dpl"      4/8  disparities per lane in k_chain and k_hfused
+//   "vdd_dpl"        0/4/8  k_vdd strip mapping (0 = choose per call from the batch size)
+//   "cost_band"      >= 8 rows per k_cost workgroup
+//   "cost_xcd", "vdd_xcd", "hf_xcd"   1/0  XCD-contiguous workgroup order of that kernel
+//   "reserve_cus"    CUs other streams keep busy while a lock-step pass runs (shrinks the frames per launch)
+//   "vdd_spin_limit" poll rounds a lane may wait in a lock-step pass (0 = 64 per row + 4096; -1 = test hook: every
+//                    workgroup reports a time-out, which drives the guard / V3D_ERR_LOCKSTEP path deterministically)
+extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
+{
+    if (!h || !key) { v3d_set_error("null argument"); return V3D_ERR_ARG; }
+    auto is = [&](const char* k) { return strcmp(key, k) == 0; };
+    auto bad = [&]() { v3d_set_error("option %s: value %d out of range", key, value); return V3D_ERR_ARG; };
+    if (is("lockstep")) { if (value != 0 && value != 1) return bad(); h->vdd_mode = value; }
+    else if (is("hfused")) { if (value != 0 && value != 1) return bad(); h->hfused = value != 0; }
+    else if (is("chain_dpl")) { if (value != 4 && value != 8) return bad(); h->dpl = value; }
+    else if (is("vdd_dpl")) { if (value != 0 && value != 4 && value != 8) return bad(); h->vdd_dpl = value; }
+    else if (is("cost_band")) { if (value < 8 || value > 65536) return bad(); h->cost_band = value; }
+    else if (is("cost_xcd")) { if (value != 0 && value != 1) return bad(); h->cost_xcd = value; }
+    else if (is("vdd_xcd")) { if (value != 0 && value != 1) return bad(); h->vdd_xcd = value; }
+    else if (is("hf_xcd")) { if (value != 0 && value != 1) return bad(); h->hf_xcd = value; }
+    else if (is("reserve_cus")) { if (value < 0 || value > h->ncu) return bad(); h->reserve_cus = value; vdd_size_launches(h); }
+    else if (is("vdd_spin_limit")) { if (value < -1) return bad(); h->vdd_spin_limit = value; }
+    else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
+    return V3D_OK;
+}
+extern "C" int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* value)
+{
+    if (!h || !key || !value) { v3d_set_error("null argument"); return V3D_ERR_ARG; }
+    auto is = [&](const char* k) { return strcmp(key, k) == 0; };
+    if (is("lockstep")) *value = vdd_usable(h) ? 1 : 0;
+    else if (is("hfused")) *value = h->hfused ? 1 : 0;
+    else if (is("chain_dpl")) *value = h->dpl;
+    else if (is("vdd_dpl")) *value = h->vdd_dpl;
+    else if (is("cost_band")) *value = h->cost_band;
+    else if (is("cost_xcd")) *value = h->cost_xcd;
+    else if (is("vdd_xcd")) *value = h->vdd_xcd;
+    else if (is("hf_xcd")) *value = h->hf_xcd;
+    else if (is("reserve_cus")) *value = h->reserve_cus;
+    else if (is("vdd_spin_limit")) *value = h->vdd_spin_limit;
+    else if (is("vdd_frames_per_launch_dpl4")) *value = h->vdd_mf4;       // read-only: the co-residency bounds in force
+    else if (is("vdd_frames_per_launch_dpl8")) *value = h->vdd_mf8;
+    else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
+    return V3D_OK;
+}
+
 extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW, int maxH, int maxB, v3d_sgbm** out)
 {
     if (!prm || !out) { v3d_set_error("null argument"); return V3D_ERR_ARG; }
@@ -1189,8 +1273,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         v3d_set_error("P2=%d / preFilterCap exceed the int16 range of the packed SGM recurrence (need 2*P2 + 25*(2*ftzero+63) < 32767)", p2);
         return V3D_ERR_UNSUPPORTED;
     }
-    const char* e = getenv("V3D_CHAIN_DPL");
-    h->dpl = (e && atoi(e) == 8) ? 8 : 4;
+    h->dpl = 4;
     const size_t px = (size_t)maxW * maxH * maxB, vol = (size_t)(maxW - V3D_D) * maxH * V3D_D * maxB;
     h->bytes = 0;
     int rc = 0;
@@ -1203,33 +1286,32 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         const size_t c4 = (size_t)v3d_cdiv(maxH, 4) * v3d_cdiv(W1m, 16) * 64 * 3, c8 = (size_t)v3d_cdiv(maxH, 8) * v3d_cdiv(W1m, 8) * 64 * 5;
         rc |= ws_alloc(&h->ckpt, (c4 > c8 ? c4 : c8) * maxB, &h->bytes);
     }
-    { const char* e2 = getenv("V3D_HFUSED"); h->hfused = !(e2 && atoi(e2) == 0); }
+    h->hfused = true;
     {
-        const char* e5 = getenv("V3D_VDD_DPL");
-        h->vdd_dpl = (e5 && (atoi(e5) == 8 || atoi(e5) == 4)) ? atoi(e5) : 0;
+        h->vdd_dpl = 0;
         const int nstrips_max = v3d_cdiv(maxW - V3D_D, 64);          // granule ring sized for the narrower strips
         const size_t ng = (size_t)maxB * nstrips_max * 2 * VDD_RING * VDD_GRAN;
         rc |= ws_alloc(&h->gran, ng, &h->bytes);
         rc |= ws_alloc(&h->vdd_err, 64, &h->bytes);
         if (!rc) { (void)hipMemset(h->gran, 0, ng * sizeof(unsigned long long)); (void)hipMemset(h->vdd_err, 0, 64 * sizeof(int)); }
+        h->err_host = nullptr;
+        if (!rc && hipHostMalloc((void**)&h->err_host, 64, hipHostMallocDefault) != hipSuccess) { h->err_host = nullptr; rc = 1; }
+        if (h->err_host) *h->err_host = 0;
+        h->vdd_done_ev = nullptr; h->vdd_ev_recorded = false;
+        if (!rc && hipEventCreateWithFlags(&h->vdd_done_ev, hipEventDisableTiming) != hipSuccess) { h->vdd_done_ev = nullptr; rc = 1; }
         h->vdd_seq = 1;
-        const char* e4 = getenv("V3D_VDD");
-        h->vdd_mode = (e4 && atoi(e4) == 0) ? 0 : 1;      // default on; V3D_VDD=0 falls back to three k_chain launches
+        h->vdd_mode = 1;                                  // lock-step pass on; option "lockstep" = 0 falls back to three k_chain launches
+        h->reserve_cus = 0; h->vdd_spin_limit = 0;
         // all strips of a launch must be resident together: bound frames per launch by the occupancy query, with margin
         int b4 = 0, b8 = 0, ncu = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_vdd<4, true>, 1024, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, k_vdd<8, true>, 1024, 0);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-        if (b4 > 2) b4 = 2;
-        if (b8 > 2) b8 = 2;
-        h->vdd_mf4 = (b4 * ncu * 9 / 10) / v3d_cdiv(maxW - V3D_D, 64);
-        h->vdd_mf8 = (b8 * ncu * 9 / 10) / v3d_cdiv(maxW - V3D_D, 128);
-        if (h->vdd_mf4 < 1 || h->vdd_mf8 < 1) h->vdd_mode = 0;
+        h->vdd_occ4 = b4 > 2 ? 2 : b4; h->vdd_occ8 = b8 > 2 ? 2 : b8; h->ncu = ncu;
+        vdd_size_launches(h);
     }
-    { const char* e7 = getenv("V3D_VDD_XCD"); h->vdd_xcd = e7 ? atoi(e7) : 0; }
-    { const char* e9 = getenv("V3D_HF_XCD"); h->hf_xcd = e9 ? atoi(e9) : 0; }
-    { const char* e8 = getenv("V3D_COST_XCD"); h->cost_xcd = e8 ? atoi(e8) : 1; }
-    { const char* e6 = getenv("V3D_COST_BAND"); h->cost_band = e6 && atoi(e6) >= 8 ? atoi(e6) : 90; }
+    h->vdd_xcd = 0; h->hf_xcd = 0; h->cost_xcd = 1;      // measured: XCD-contiguous order pays for k_cost only
+    h->cost_band = 90;
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
     *out = h;
     return V3D_OK;
@@ -1241,6 +1323,8 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
     (void)hipSetDevice(h->device);
     void* ptrs[] = { h->rec, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt, h->gran, h->vdd_err };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->err_host) (void)hipHostFree(h->err_host);
+    if (h->vdd_done_ev) (void)hipEventDestroy(h->vdd_done_ev);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -1285,10 +1369,24 @@ static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t 
         v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
         v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
         v.gran = h->gran; v.err = h->vdd_err; v.xcd = h->vdd_xcd;
+        v.spin_limit = h->vdd_spin_limit != 0 ? h->vdd_spin_limit : VDD_SPIN_PER_ROW * H + VDD_SPIN_SLACK;
         const dim3 grid(v.nstrips * nf), block(1024);
         if (dpl == 8) { if (rev) hipLaunchKernelGGL((k_vdd<8, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<8, false>), grid, block, 0, st, v); }
         else { if (rev) hipLaunchKernelGGL((k_vdd<4, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<4, false>), grid, block, 0, st, v); }
     }
+}
+
+// A lock-step pass of an earlier call timed out (k_vdd_guard raised the host flag): that call's output was
+// invalidated on the device, and the handle refuses further work until the host has reacted --
+// v3d_sgbm_set_lockstep(h, 0 or 1) clears the state.  No synchronisation here: one read of pinned memory.
+static int lockstep_state(const v3d_sgbm* h)
+{
+    if (h->err_host && *(volatile int*)h->err_host != 0) {
+        v3d_set_error("a lock-step SGM pass of an earlier call timed out (%d workgroups): its output was set to INVALID; "
+                      "call v3d_sgbm_set_lockstep(h, 0) and recompute", *(volatile int*)h->err_host);
+        return V3D_ERR_LOCKSTEP;
+    }
+    return V3D_OK;
 }
 
 // stages: 1 = cost volume, 2 = aggregation + WTA + LR check (raw), 3 = median + speckles (final)
@@ -1298,6 +1396,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     int rc = check_geometry(h, n, W, H, pitch);
     if (rc) return rc;
     if (!left || !right || !out) { v3d_set_error("null image pointer"); return V3D_ERR_ARG; }
+    if ((rc = lockstep_state(h)) != V3D_OK) return rc;
     const int W1 = W - V3D_D;
     const int px = W * H;
 
@@ -1315,7 +1414,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     a.dispw = h->dispw; a.d2key = h->d2key; a.xcd = h->hf_xcd;
     V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
-    const bool use_vdd = h->vdd_mode && H < 4095;
+    const bool use_vdd = vdd_usable(h) && H < 4095;
     if (use_vdd) {
         // r1 + r2 + r3 in one lock-step pass (k_vdd); frames per launch bounded by co-residency
         // mapping: 4 disparities per lane (64-column strips) while the whole batch fits one co-resident launch, else
@@ -1323,6 +1422,8 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         launch_vdd(h, n, W1, H, false, st);
         prof_mark(h, ST_D1, st);
         prof_mark(h, ST_D3, st);
+        V3D_HIP_CHECK(hipEventRecord(h->vdd_done_ev, st));       // v3d_sgbm_stream_wait_lockstep: other streams may order behind the pass
+        h->vdd_ev_recorded = true;
     } else {
     launch_chain<false, 0, false, 0>(h, a, st);         // r2: (x, y-1)
     prof_mark(h, ST_D1, st);
@@ -1337,6 +1438,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         if (use_vdd) {
             launch_vdd(h, n, W1, H, true, st);              // (x-1,y+1), (x,y+1), (x+1,y+1) in one bottom-up lock-step pass
             prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st);
+            V3D_HIP_CHECK(hipEventRecord(h->vdd_done_ev, st));
         } else {
             launch_chain<false, 0, true, 1>(h, a, st);      // (x, y+1)
             prof_mark(h, ST_D1R, st);
@@ -1355,6 +1457,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     prof_mark(h, ST_LRCHECK, st);
     if (last_stage == 2) {
         hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, out);
+        if (use_vdd) hipLaunchKernelGGL(k_vdd_guard, dim3(256), dim3(256), 0, st, h->vdd_err, h->err_host, out, (size_t)px * n);
         V3D_LAUNCH_CHECK();
         prof_mark(h, ST_MEDIAN, st);
         return V3D_OK;
@@ -1367,6 +1470,10 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
         const int newVal = (h->prm.minDisparity - 1) * 16, maxDiff = 16 * h->prm.speckleRange, maxSize = h->prm.speckleWindowSize;
         rc = launch_speckles(out, W, H, n, newVal, maxSize, maxDiff, h->labels, st);
         if (rc) return rc;
+    }
+    if (use_vdd) {                                      // time-outs of this (or an earlier, uncleared) pass: poison `out`, raise the host flag
+        hipLaunchKernelGGL(k_vdd_guard, dim3(256), dim3(256), 0, st, h->vdd_err, h->err_host, out, (size_t)px * n);
+        V3D_LAUNCH_CHECK();
     }
     prof_mark(h, V3D_NSTAGE, st);
     if (h->prof_on && h->prof_calls < V3D_PROF_MAX_CALLS) h->prof_calls++;
@@ -1392,7 +1499,27 @@ extern "C" int v3d_sgbm_set_lockstep(v3d_sgbm* h, int enable)
     V3D_HIP_CHECK(hipSetDevice(h->device));
     V3D_HIP_CHECK(hipDeviceSynchronize());
     V3D_HIP_CHECK(hipMemset(h->vdd_err, 0, sizeof(int)));
-    h->vdd_mode = (enable && h->vdd_mf4 >= 1 && h->vdd_mf8 >= 1) ? 1 : 0;
+    *(volatile int*)h->err_host = 0;
+    h->vdd_mode = enable ? 1 : 0;
+    return V3D_OK;
+}
+
+// non-blocking: > 0 once k_vdd_guard of a finished call has seen time-outs (the flag travels with the call's last launch)
+extern "C" int v3d_sgbm_poll_errors(const v3d_sgbm* h)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    return h->err_host ? *(volatile int*)h->err_host : 0;
+}
+
+// make `stream` wait until the lock-step pass of the most recent compute call on this handle has finished (no-op if
+// none ran).  For hosts that run a collective on a side stream: RCCL workgroups that land on a CU take a slot the
+// co-resident pass was sized with, so order the collective BEHIND the pass (it then overlaps the horizontal pass,
+// the post-filters and the upscale instead) and the next compute call behind the collective.
+extern "C" int v3d_sgbm_stream_wait_lockstep(v3d_sgbm* h, void* stream)
+{
+    if (!h) { v3d_set_error("null handle"); return V3D_ERR_ARG; }
+    if (!h->vdd_ev_recorded) return V3D_OK;
+    V3D_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->vdd_done_ev, 0));
     return V3D_OK;
 }
 

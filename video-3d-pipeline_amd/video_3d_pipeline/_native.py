@@ -23,11 +23,20 @@ EXPORTS = (
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
     "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch",
     "v3d_sgbm_sync_errors", "v3d_sgbm_set_lockstep", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
+    "v3d_mono_blend_ws_bytes", "v3d_mono_blend", "v3d_mono_blend_batch",
+    "v3d_sgbm_poll_errors", "v3d_sgbm_stream_wait_lockstep", "v3d_sgbm_set_option", "v3d_sgbm_get_option", "v3d_set_option",
 )
+
+ERR_LOCKSTEP = -4      # V3D_ERR_LOCKSTEP
 
 
 class NativeError(RuntimeError):
     pass
+
+
+class LockstepTimeout(NativeError):
+    """a lock-step SGM pass timed out on an over-subscribed GPU; the call's output was invalidated on the device.
+    React with StereoSGBM.set_lockstep(False) and recompute (include/v3d_hip.h)."""
 
 
 class SgbmParams(C.Structure):
@@ -64,6 +73,15 @@ def lib():
         L.v3d_sgbm_profile.argtypes = [vp, ci]
         L.v3d_sgbm_sync_errors.argtypes = [vp]
         L.v3d_sgbm_set_lockstep.argtypes = [vp, C.c_int]
+        L.v3d_sgbm_poll_errors.argtypes = [vp]
+        L.v3d_sgbm_stream_wait_lockstep.argtypes = [vp, vp]
+        L.v3d_sgbm_set_option.argtypes = [vp, C.c_char_p, ci]
+        L.v3d_sgbm_get_option.argtypes = [vp, C.c_char_p, C.POINTER(ci)]
+        L.v3d_set_option.argtypes = [C.c_char_p, ci]
+        L.v3d_mono_blend_ws_bytes.argtypes = [ci]
+        L.v3d_mono_blend_ws_bytes.restype = sz
+        L.v3d_mono_blend.argtypes = [vp, ci, ci, vp, ci, ci, C.c_float, C.c_float, vp, vp, vp]
+        L.v3d_mono_blend_batch.argtypes = [vp, ci, ci, ci, vp, ci, ci, sz, C.c_float, C.c_float, vp, vp, vp]
         L.v3d_sgbm_profile_stage_name.argtypes = [ci]
         L.v3d_sgbm_profile_stage_name.restype = C.c_char_p
         L.v3d_sgbm_profile_read.argtypes = [vp, C.POINTER(C.c_double), ci]
@@ -91,7 +109,13 @@ def lib():
 
 def _check(rc, what):
     if rc != 0:
-        raise NativeError(f"{what} failed (rc={rc}): {lib().v3d_last_error().decode()}")
+        cls = LockstepTimeout if rc == ERR_LOCKSTEP else NativeError
+        raise cls(f"{what} failed (rc={rc}): {lib().v3d_last_error().decode()}")
+
+
+def set_option(key, value):
+    """library-wide tuning switch (v3d_set_option): gf_band1, gf_band2, gf_tiled, gf_fused, corr_gather"""
+    _check(lib().v3d_set_option(key.encode(), int(value)), f"v3d_set_option({key})")
 
 
 def _stream():
@@ -104,6 +128,17 @@ def _dev(t, dtype, what):
     if t.dtype != dtype or not t.is_contiguous():
         raise NativeError(f"{what}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
     return C.c_void_p(t.data_ptr())
+
+
+def resolve_device(device=None):
+    """one place that turns None / 'cuda' / 'cuda:i' / i / torch.device into a device WITH an index: a bare 'cuda'
+    means the CURRENT device (torch.cuda.set_device), never silently GPU 0"""
+    if isinstance(device, int):
+        return torch.device("cuda", device)
+    d = torch.device("cuda") if device is None else torch.device(device)
+    if d.type != "cuda":
+        raise NativeError(f"device {device!r}: this build only has the MI355X (HIP) path")
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def default_params(**kw):
@@ -120,14 +155,34 @@ class StereoSGBM:
     """GPU stand-in for the object cv2.StereoSGBM_create returns (depth.py:315-325); `.compute`
     mirrors depth.py:341 on device tensors."""
 
-    def __init__(self, max_width, max_height, max_batch=1, device=0, **params):
+    def __init__(self, max_width, max_height, max_batch=1, device=None, options=None, **params):
+        """device: None = the current device (what torch.cuda.set_device / LOCAL_RANK selected), an index, or a
+        torch.device; options: {key: int} for v3d_sgbm_set_option (tuning switches, results never change)"""
         self.params = default_params(**params)
         self.max_width, self.max_height, self.max_batch = int(max_width), int(max_height), int(max_batch)
-        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self.device = resolve_device(device)
         h = C.c_void_p()
         _check(lib().v3d_sgbm_create(C.byref(self.params), self.device.index, self.max_width, self.max_height,
                                      self.max_batch, C.byref(h)), "v3d_sgbm_create")
         self._h = h
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        _check(lib().v3d_sgbm_set_option(self._h, key.encode(), int(value)), f"v3d_sgbm_set_option({key})")
+
+    def get_option(self, key):
+        v = C.c_int()
+        _check(lib().v3d_sgbm_get_option(self._h, key.encode(), C.byref(v)), f"v3d_sgbm_get_option({key})")
+        return v.value
+
+    def poll_errors(self):
+        """non-blocking: lock-step time-outs reported so far by finished calls (0 = healthy)"""
+        return int(lib().v3d_sgbm_poll_errors(self._h))
+
+    def stream_wait_lockstep(self, stream):
+        """make the torch stream `stream` wait for the lock-step pass of the latest compute() (order collectives behind it)"""
+        _check(lib().v3d_sgbm_stream_wait_lockstep(self._h, C.c_void_p(stream.cuda_stream)), "v3d_sgbm_stream_wait_lockstep")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -270,6 +325,26 @@ def disp_to_depth(disp16, out=None):
     _check(lib().v3d_disp_to_depth(_dev(disp16, torch.int16, "disp16"), disp16.numel(), _dev(out, torch.float32, "out"),
                                    _stream()), "v3d_disp_to_depth")
     return out
+
+
+def mono_blend(disp16, mono, w_stereo=0.7, w_mono=0.3, out=None):
+    """depth.py:344-374 on the device.  disp16: int16 [H,W] or [N,H,W]; mono: float32 [mh,mw] or [N,mh,mw] (any size)
+    -> float32 depth like disp16's shape: clamp0(w_stereo * disp16/16 + w_mono * minmax64(resize(mono)))"""
+    batched = disp16.dim() == 3
+    d3 = disp16 if batched else disp16[None]
+    m3 = mono if mono.dim() == 3 else mono[None]
+    n, H, W = d3.shape
+    if m3.shape[0] != n:
+        raise NativeError(f"mono batch {m3.shape[0]} != disparity batch {n}")
+    mh, mw = m3.shape[1:]
+    if out is None:
+        out = torch.empty(d3.shape, dtype=torch.float32, device=d3.device)
+    o3 = out if out.dim() == 3 else out[None]
+    ws = torch.empty(max(int(lib().v3d_mono_blend_ws_bytes(n)), 16), dtype=torch.uint8, device=d3.device)
+    _check(lib().v3d_mono_blend_batch(_dev(d3, torch.int16, "disp16"), n, W, H, _dev(m3, torch.float32, "mono"), mw, mh, mh * mw,
+                                      float(w_stereo), float(w_mono), _dev(o3, torch.float32, "out"), _dev(ws, torch.uint8, "ws"),
+                                      _stream()), "v3d_mono_blend_batch")
+    return out if batched else o3[0]
 
 
 def depth_to_u16(depth):

@@ -11,9 +11,11 @@ behaviour, CLI flags) with the per-frame arithmetic moved from OpenCV-on-CPU to 
 
 There is no CPU compute path: without a GPU (or without libv3d_hip.so) construction fails loudly,
 like the reference's `RuntimeError("CUDA not available but requested")` (depth.py:43-44).
-Neural guidance (the reference's DPT blend, depth.py:344-371) needs weights fetched by model name and
-is out of scope: the flags are kept and the loader falls back to stereo-only exactly
-like the reference does when loading fails (depth.py:107-114).
+Neural guidance (the reference's DPT blend, depth.py:344-371): the blend itself -- resize of the monocular map,
+min-max to the disparity range, 0.7 / 0.3 mix, clamp -- runs on the GPU (v3d_mono_blend).  The monocular map comes
+from a provider: `DPTForDepthEstimation` loaded from a LOCAL directory (or an already populated HF cache; nothing is
+ever downloaded), or any callable handed to the constructor (`mono_provider`).  When neither is available the loader
+falls back to stereo-only exactly like the reference does when loading fails (depth.py:107-114).
 """
 import argparse
 import hashlib
@@ -37,7 +39,9 @@ class HipStereoBackend:
         self.torch = torch
         self.native = _native
         _native.lib()                                  # fail now, loudly, if the HIP library is missing
-        self.device = torch.device(device)
+        # resolved ONCE: a bare "cuda" is the current device (what torch.cuda.set_device / LOCAL_RANK selected), and
+        # tensors, the matcher's workspace and its kernels all live on that same index
+        self.device = _native.resolve_device(device)
         self.sgbm_params = dict(sgbm_params or {})
         self._matcher = None
         self._geom = None
@@ -47,7 +51,7 @@ class HipStereoBackend:
         if self._matcher is None or g[0] < W or g[1] < H or g[2] < n:
             if self._matcher is not None:
                 self._matcher.close()
-            self._matcher = self.native.StereoSGBM(W, H, n, device=self.device.index or 0, **self.sgbm_params)
+            self._matcher = self.native.StereoSGBM(W, H, n, device=self.device, **self.sgbm_params)
             self._geom = (W, H, n)
         return self._matcher
 
@@ -70,8 +74,29 @@ class HipStereoBackend:
         L, R = self.native.split_sbs(d, unsqueeze)
         return L.cpu().numpy(), R.cpu().numpy()
 
-    def pairs_to_disparity(self, pairs: List[Tuple[np.ndarray, np.ndarray]]) -> List[np.ndarray]:
-        """BGR (left, right) pairs -> float32 disparity maps (>= 0), depth.py:337-341 + 374"""
+    def _depth_from(self, disp, monos, out=None):
+        """disp16 [n,H,W] -> float32 depth: /16 + clamp (depth.py:341, 374), or, with monocular maps, the hybrid blend
+        of depth.py:344-374 (maps of one shape go through one batched launch set)"""
+        torch, nat = self.torch, self.native
+        if monos is None:
+            return nat.disp_to_depth(disp, out)
+        if len(monos) != disp.shape[0]:
+            raise ValueError(f"{len(monos)} monocular maps for {disp.shape[0]} frames")
+        ms = [m if torch.is_tensor(m) else torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)) for m in monos]
+        ms = [m.to(self.device, torch.float32).contiguous() for m in ms]
+        if any(m.dim() != 2 for m in ms):
+            raise ValueError("monocular depth maps must be 2-D")
+        if out is None:
+            out = torch.empty(disp.shape, dtype=torch.float32, device=self.device)
+        if len({tuple(m.shape) for m in ms}) == 1:
+            nat.mono_blend(disp, torch.stack(ms), 0.7, 0.3, out)
+        else:
+            for i, m in enumerate(ms):
+                nat.mono_blend(disp[i], m, 0.7, 0.3, out[i])
+        return out
+
+    def pairs_to_disparity(self, pairs: List[Tuple[np.ndarray, np.ndarray]], monos=None) -> List[np.ndarray]:
+        """BGR (left, right) pairs -> float32 disparity maps (>= 0), depth.py:337-341 + 374 (+ 344-371 with `monos`)"""
         torch, nat = self.torch, self.native
         n = len(pairs)
         H, W = pairs[0][0].shape[:2]
@@ -86,7 +111,7 @@ class HipStereoBackend:
             disp = matcher.compute(lg, rg)
             if matcher.sync_errors():
                 raise RuntimeError("SGM kernels report time-outs with the lock-step pass off: device fault")
-        depth = nat.disp_to_depth(disp)
+        depth = self._depth_from(disp, monos)
         out = depth.cpu().numpy()
         return [out[i] for i in range(n)]
 
@@ -100,9 +125,10 @@ class HipStereoBackend:
             bufs[key] = t
         return t
 
-    def sbs_to_disparity(self, frames: List[np.ndarray], unsqueeze: bool):
+    def sbs_to_disparity(self, frames: List[np.ndarray], unsqueeze: bool, mono_provider=None):
         """fused path: SBS BGR frames -> device float32 disparity [n,H,W] (no BGR halves materialised).
-        Frames are gathered into one pinned buffer and cross PCIe in a single asynchronous copy."""
+        Frames are gathered into one pinned buffer and cross PCIe in a single asynchronous copy.
+        mono_provider (neural guidance on): called with the left views as RGB arrays, its maps are blended in."""
         torch, nat = self.torch, self.native
         n = len(frames)
         H, W = frames[0].shape[:2]
@@ -122,7 +148,11 @@ class HipStereoBackend:
             disp = matcher.compute(lg, rg, self._staging("disp", (n, H, ow), torch.int16, False))
             if matcher.sync_errors():
                 raise RuntimeError("SGM kernels report time-outs with the lock-step pass off: device fault")
-        depth = nat.disp_to_depth(disp, self._staging("depth", (n, H, ow), torch.float32, False))
+        monos = None
+        if mono_provider is not None:
+            lefts = [nat.split_sbs(dev[i], unsqueeze)[0].flip(-1).cpu().numpy() for i in range(n)]     # left view, RGB (depth.py:274)
+            monos = mono_provider(lefts)
+        depth = self._depth_from(disp, monos, self._staging("depth", (n, H, ow), torch.float32, False))
         return depth
 
     def depth_to_host(self, depth) -> np.ndarray:
@@ -150,7 +180,10 @@ class HybridStereoDepthExtractor:
                  use_neural_guidance: bool = True,
                  stereo_only: bool = False,
                  unsqueeze_sbs: bool = True,
-                 backend=None):
+                 backend=None,
+                 mono_provider=None):
+        """ mono_provider: optional callable(list of HxWx3 uint8 RGB left views) -> list of 2-D float32 monocular
+        depth maps (NumPy arrays or device tensors, any size); takes the place of the DPT forward of depth.py:348-350 """
 
         self.device = device
         self.work_dir = create_work_directory(work_dir)
@@ -175,23 +208,63 @@ class HybridStereoDepthExtractor:
         print(f"Neural guidance: {self.use_neural_guidance and not self.stereo_only}")
 
         self.model = None
+        self.processor = None
+        self.mono_provider = mono_provider
         self.model_loaded = False
         self.max_vram_usage = 0.9
         self.memory_stats = defaultdict(float)
 
     def load_model(self):
-        """ Load depth estimation model (neural guidance is unavailable offline: stereo-only fallback) """
+        """ Load depth estimation model (depth.py:60-114).  Offline by construction: a local directory, a model already in
+        the HF cache, or a provider handed to the constructor; anything else falls back like depth.py:107-114 """
         if self.model_loaded:
             return
         if self.stereo_only:
             print("Using stereo-only mode (no neural network)")
             self.model_loaded = True
             return
+        if self.mono_provider is not None:
+            print("Using the supplied monocular depth provider for neural guidance")
+            self.model_loaded = True
+            return
         print(f"Loading depth model: {self.model_checkpoint}")
-        print("Warning: Failed to load neural model, falling back to stereo-only mode: "
-              "neural guidance weights are fetched by name and are not part of this build")
-        self.stereo_only = True
-        self.model_loaded = True
+        try:
+            from transformers import DPTForDepthEstimation, DPTImageProcessor
+            print("Loading DPT model for neural depth guidance")
+            self.processor = DPTImageProcessor.from_pretrained(self.model_checkpoint, local_files_only=True)
+            self.model = DPTForDepthEstimation.from_pretrained(self.model_checkpoint, local_files_only=True)
+            dev = getattr(self.backend, "device", self.device)
+            self.model = self.model.to(dev)
+            self.model.eval()
+            self.mono_provider = self._dpt_provider
+            self.model_loaded = True
+            print("✓ Model loaded successfully")
+        except ImportError:
+            print("Warning: transformers library not available, falling back to stereo-only mode")
+            self.stereo_only = True
+            self.model_loaded = True
+        except Exception as e:
+            print(f"Warning: Failed to load neural model, falling back to stereo-only mode: {e}")
+            self.stereo_only = True
+            self.model_loaded = True
+
+    def _dpt_provider(self, left_rgb_frames):
+        """ depth.py:283-293 + 346-350: DPT forward on the left view; the predicted depth stays on the device """
+        import torch
+        dev = next(self.model.parameters()).device
+        out = []
+        with torch.no_grad():
+            for rgb in left_rgb_frames:
+                inputs = self.processor(images=rgb, return_tensors="pt")
+                inputs = {k: v.to(dev) for k, v in inputs.items()}
+                out.append(self.model(**inputs).predicted_depth[0].float())
+        return out
+
+    def _guidance_provider(self):
+        """ the provider when neural guidance is active (depth.py:344-345), else None """
+        if self.use_neural_guidance and not self.stereo_only and self.mono_provider is not None:
+            return self.mono_provider
+        return None
 
     def get_cache_path(self, video_path: str, frame_start: int, frame_count: int) -> Path:
         """ Generate cache path for depth maps (key format identical to depth.py:119-120) """
@@ -247,7 +320,7 @@ class HybridStereoDepthExtractor:
         return self.backend.split_sbs(np.ascontiguousarray(sbs_frame), unsqueeze)
 
     def preprocess_frame_pair(self, left_frame: np.ndarray, right_frame: np.ndarray) -> Dict:
-        """ Preprocess frame pair for depth estimation (BGR -> RGB views; no neural inputs in this build) """
+        """ Preprocess frame pair for depth estimation (BGR -> RGB views; the provider does its own input processing) """
         if left_frame.shape[2] == 3:
             left_rgb, right_rgb = left_frame[..., ::-1], right_frame[..., ::-1]
         else:
@@ -263,7 +336,15 @@ class HybridStereoDepthExtractor:
         if batch_size == 0:
             return []
         try:
-            depth_maps = self.backend.pairs_to_disparity(frame_pairs)
+            monos = None
+            provider = self._guidance_provider()
+            if provider is not None:
+                try:
+                    monos = provider([np.ascontiguousarray(l[..., ::-1]) for l, _ in frame_pairs])     # left views as RGB (depth.py:274)
+                except Exception as e:                       # depth.py:367-369
+                    print(f"    Warning: Neural guidance failed, using stereo only: {e}")
+            depth_maps = self.backend.pairs_to_disparity(frame_pairs, monos) if monos is not None \
+                else self.backend.pairs_to_disparity(frame_pairs)
         except Exception as e:
             print(f"Error processing frame batch: {e}")
             raise
@@ -297,8 +378,10 @@ class HybridStereoDepthExtractor:
             self.load_model()
 
         rank, world = sharding.rank_world()
+        sharding.require_initialized(world)                  # WORLD_SIZE > 1 without a process group would race the cache dir
         processed_count = 0
         batch, batch_idx = [], []
+        provider = self._guidance_provider()
         # PNG compression (zlib) costs ~20 ms per 1080p map on one core, the GPU path 0.5 ms: the maps of a batch go to
         # a bounded pool of writer threads and compress while the next batch is decoded and computed
         writers = PngWriterPool()
@@ -307,7 +390,10 @@ class HybridStereoDepthExtractor:
             nonlocal processed_count
             if not batch:
                 return
-            depth = self.backend.sbs_to_disparity(batch, self.unsqueeze_sbs)
+            if provider is not None:
+                depth = self.backend.sbs_to_disparity(batch, self.unsqueeze_sbs, provider)
+            else:
+                depth = self.backend.sbs_to_disparity(batch, self.unsqueeze_sbs)
             for j, frame_idx in enumerate(batch_idx):
                 writers.submit(cache_path / f"depth_{frame_idx:06d}.png", self.backend.normalise_u16(depth[j]))
                 processed_count += 1
@@ -315,18 +401,19 @@ class HybridStereoDepthExtractor:
             batch.clear()
             batch_idx.clear()
 
-        seen = 0
+        # frame i -> rank i mod world (round-robin): every rank seeks to and decodes ONLY its own frames, so the decode
+        # (the scaling limiter once the kernels are fast) is divided by the world size, not replicated
+        decoded = 0
         with writers:
-            for i, frame in enumerate(iter_frames(video_path, start_frame, frame_count)):
-                seen += 1
-                if not sharding.owns(i, rank, world):          # frame i -> rank i mod world (round-robin)
-                    continue
+            for k, frame in enumerate(iter_frames(video_path, start_frame, frame_count, stride=world, offset=rank)):
+                decoded += 1
                 batch.append(frame)
-                batch_idx.append(i)
+                batch_idx.append(rank + k * world)
                 if len(batch) == self.batch_size:
                     flush()
             flush()
-        if seen == 0:
+        self.last_decoded_frames = decoded
+        if sharding.total(decoded) == 0:
             raise ValueError("No frames extracted from video")
         sharding.barrier()
 
@@ -361,6 +448,8 @@ def main(argv=None):
     unsqueeze_sbs = not args.no_unsqueeze
 
     try:
+        from . import sharding
+        sharding.init_process_group()            # no-op for one process; under torchrun: one rank per GPU (sets the device)
         extractor = HybridStereoDepthExtractor(
             model_checkpoint=args.model, work_dir=args.work_dir, cache_dir=args.work_dir, device=args.device,
             batch_size=args.batch_size, use_neural_guidance=use_neural_guidance, stereo_only=stereo_only,

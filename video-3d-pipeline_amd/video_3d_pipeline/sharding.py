@@ -7,6 +7,7 @@ real exchange is the 4K guide: rank 0 decodes a round of `world` guide frames an
 round over RCCL/xGMI (root -> 7 peers uses all 7 links in parallel); each rank keeps its own frame.
 """
 import os
+from collections import deque
 
 import numpy as np
 
@@ -22,6 +23,22 @@ def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _initialized() -> bool:
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except ImportError:
+        return False
+
+
+def require_initialized(world: int) -> None:
+    """A world of several ranks needs a live process group: with WORLD_SIZE > 1 only in the environment the barriers
+    would be no-ops and the guide exchange would silently hand every rank but 0 a flat guide.  Fail loudly."""
+    if world > 1 and not _initialized():
+        raise RuntimeError(f"WORLD_SIZE={world} but torch.distributed is not initialised: call "
+                           "video_3d_pipeline.sharding.init_process_group() first (the CLIs do)")
+
+
 def owns(frame_idx: int, rank: int, world: int) -> bool:
     return frame_idx % world == rank
 
@@ -31,7 +48,8 @@ def my_frames(n_frames: int, rank: int, world: int):
 
 
 def init_process_group(backend=None):
-    """one process per GPU; backend 'nccl' is RCCL on ROCm, 'gloo' for CPU rehearsals"""
+    """one process per GPU; backend 'nccl' is RCCL on ROCm, 'gloo' for CPU rehearsals.  Sets the current device to
+    LOCAL_RANK so that every later "cuda" resolves to this rank's GPU (see _native.resolve_device)."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
@@ -46,38 +64,141 @@ def init_process_group(backend=None):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend, device_id=torch.device("cuda", torch.cuda.current_device()))
     else:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend)
 
 
 def barrier():
-    try:
+    rank, world = rank_world()
+    require_initialized(world)
+    if world > 1:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            dist.barrier()
-    except ImportError:
-        pass
+        dist.barrier()
+
+
+def total(value: int) -> int:
+    """sum of a per-rank integer over the world (host-side bookkeeping, e.g. decoded-frame counts)"""
+    rank, world = rank_world()
+    require_initialized(world)
+    if world == 1:
+        return int(value)
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+class GuideRoundExchange:
+    """The one collective of the path: rank `src` decodes a round of `world` 4K guide frames, one broadcast
+    hands the round to every rank, rank r keeps frame r.
+
+    * the luma never leaves the device on the root: `post` copies device tensors into the round buffer;
+    * persistent, double-buffered `[world*H*W + 16]` uint8 round buffers -- no allocation per round;
+    * ONE collective per round: which frames of the round exist (ragged end of the clip) travels in the 16 trailing
+      bytes of the same buffer;
+    * the collective runs on a side stream, so `post(round r+1)` overlaps the compute of round r; `take()` makes the
+      current stream wait for the oldest posted round and returns this rank's frame (a private copy) or None.
+    On the CPU (`gloo` rehearsals) the same calls run synchronously."""
+
+    META = 16
+
+    def __init__(self, shape, device, src=0, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world = rank_world()
+        require_initialized(self.world)
+        self.H, self.W = int(shape[0]), int(shape[1])
+        self.device = torch.device(device)
+        self.src, self.depth = src, depth
+        self.cuda = self.device.type == "cuda"
+        n = self.world * self.H * self.W
+        self._bufs = [torch.zeros(n + self.META, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self._meta_host = [torch.zeros(self.META, dtype=torch.uint8).pin_memory() if self.cuda else None for _ in range(depth)]
+        self._free_ev = [None] * depth            # slot may be overwritten once this event has passed (consumer copy done)
+        self._side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._pending = deque()
+        self._posted = 0
+        self._dist = dist
+
+    def post(self, round_frames=None):
+        """enqueue one round.  On `src`: a list of up to `world` entries, each a HxW uint8 device tensor / NumPy array or
+        None (no such frame); other ranks pass nothing."""
+        import torch
+        slot = self._posted % self.depth
+        self._posted += 1
+        buf = self._bufs[slot]
+        n = self.world * self.H * self.W
+        cur = torch.cuda.current_stream(self.device) if self.cuda else None
+        if self.cuda and self._free_ev[slot] is not None:
+            cur.wait_event(self._free_ev[slot])
+            self._side.wait_event(self._free_ev[slot])
+        if self.rank == self.src:
+            frames = list(round_frames or [])[:self.world]
+            valid = np.zeros(self.META, np.uint8)
+            view = buf[:n].view(self.world, self.H, self.W)
+            for i, f in enumerate(frames):
+                if f is None:
+                    continue
+                t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
+                if tuple(t.shape) != (self.H, self.W) or t.dtype != torch.uint8:
+                    raise ValueError(f"guide frame {i}: expected uint8 {self.H}x{self.W}, got {t.dtype} {tuple(t.shape)}")
+                view[i].copy_(t, non_blocking=True)
+                valid[i // 8] |= 1 << (i % 8)
+            if self.world > 8 * self.META:
+                raise ValueError("world too large for the validity bitmap")
+            buf[n:].copy_(torch.from_numpy(valid), non_blocking=False)
+            if self.cuda:
+                e = torch.cuda.Event()
+                e.record(cur)
+                self._side.wait_event(e)
+        if self.cuda:
+            with torch.cuda.stream(self._side):
+                self._dist.broadcast(buf, src=self.src)
+                self._meta_host[slot].copy_(buf[n:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+        else:
+            self._dist.broadcast(buf, src=self.src)
+            ev = None
+        self._pending.append((slot, ev))
+
+    def take(self):
+        """this rank's frame of the oldest posted round as a private HxW uint8 tensor, or None if the clip had none"""
+        import torch
+        slot, ev = self._pending.popleft()
+        buf = self._bufs[slot]
+        n = self.world * self.H * self.W
+        if self.cuda:
+            ev.synchronize()                              # normally long past: the round was posted one round ago
+            meta = self._meta_host[slot].numpy()
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        else:
+            meta = buf[n:].numpy()
+        if not (int(meta[self.rank // 8]) >> (self.rank % 8)) & 1:
+            return None
+        out = buf[:n].view(self.world, self.H, self.W)[self.rank].clone()
+        if self.cuda:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(self.device))
+            self._free_ev[slot] = e
+        return out
 
 
 def broadcast_guide_round(round_frames, shape, device, src=0):
-    """Rank `src` passes a list of `world` guide frames (HxW uint8 arrays, None-padded at the tail of
-    the clip); every rank gets back its own frame as a device tensor (or None).  One broadcast of
-    the whole round [world, H, W] u8, as BASELINE.json's north_star specifies."""
+    """One-shot form of GuideRoundExchange (kept for callers that exchange a single round): rank `src` passes a list of
+    `world` guide frames (None-padded at the tail of the clip); every rank gets back its own frame as a device tensor
+    (or None)."""
     import torch
-    import torch.distributed as dist
     rank, world = rank_world()
-    H, W = shape
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    require_initialized(world)
+    if world == 1:
         f = round_frames[0] if round_frames else None
-        if f is None or not isinstance(f, np.ndarray):          # already a device tensor (single-rank fast path)
+        if f is None or torch.is_tensor(f):
             return f
         return torch.from_numpy(np.ascontiguousarray(f)).to(device)
-    buf = torch.zeros((world, H, W), dtype=torch.uint8, device=device)
-    valid = torch.zeros(world, dtype=torch.uint8, device=device)
-    if rank == src:
-        for i, f in enumerate(round_frames[:world]):
-            if f is not None:
-                buf[i] = torch.from_numpy(np.ascontiguousarray(f)).to(device)
-                valid[i] = 1
-    dist.broadcast(buf, src=src)
-    dist.broadcast(valid, src=src)
-    return buf[rank].clone() if int(valid[rank]) else None
+    ex = GuideRoundExchange(shape, device, src=src, depth=1)
+    ex.post(round_frames if rank == src else None)
+    return ex.take()

@@ -23,8 +23,25 @@ def gt_disparity(W, H):
     return d
 
 
+_pair_cache = {}
+
+
 def stereo_pair(W, H, frame_idx=0, margin=64):
-    """full-width BGR left/right views (HxWx3 u8) with L(x) ~ R(x - d*)"""
+    """full-width BGR left/right views (HxWx3 u8) with L(x) ~ R(x - d*) (read-only: the last few pairs are memoised,
+    sbs_frame and guide_frame of one index share the texture synthesis)"""
+    key = (W, H, frame_idx, margin)
+    hit = _pair_cache.get(key)
+    if hit is None:
+        hit = _stereo_pair(W, H, frame_idx, margin)
+        for a in hit:
+            a.setflags(write=False)
+        if len(_pair_cache) >= 4:
+            _pair_cache.pop(next(iter(_pair_cache)), None)
+        _pair_cache[key] = hit
+    return hit
+
+
+def _stereo_pair(W, H, frame_idx, margin):
     rng = np.random.default_rng(1234 + frame_idx)
     T = _blur(rng.integers(0, 256, (H, W + 2 * margin, 3)), 1.5)
     T = np.clip((T - 127.5) * 2.5 + 127.5, 0, 255)           # restore contrast lost to the blur

@@ -31,7 +31,7 @@ class HipUpscaleBackend:
         if not torch.cuda.is_available():
             raise RuntimeError("CUDA not available but requested")
         _native.lib()
-        self.torch, self.native, self.device = torch, _native, torch.device(device)
+        self.torch, self.native, self.device = torch, _native, _native.resolve_device(device)   # bare "cuda" = the current device
 
     def to_luma(self, frame_bgr):
         d = frame_bgr if self.torch.is_tensor(frame_bgr) else self.native.to_device(frame_bgr, self.device)
@@ -88,31 +88,64 @@ class SimpleDepthUpscaler:
         print(f"Found {len(depth_files)} depth maps")
 
         rank, world = sharding.rank_world()
+        sharding.require_initialized(world)           # never a silent single-rank fallback under torchrun
         frames_dir = Path(str(Path(output_path).with_suffix("")) + "_frames")
         frames_dir.mkdir(parents=True, exist_ok=True)
-        guides = iter_frames(video_4k_path, max(int(guide_start_frame), 0), len(depth_files)) if (video_4k_path and rank == 0) else None
         n = len(depth_files)
+        g0 = max(int(guide_start_frame), 0)
+        n_guides = 0
+        if video_4k_path:
+            info = get_video_info(video_4k_path)
+            if not info:
+                raise ValueError(f"Could not read video info: {video_4k_path}")
+            total = info.get('frames', 0) or int(info['duration'] * info['fps'])
+            n_guides = max(0, min(n, total - g0))     # depth frames [0, n_guides) have a 4K frame; the rest are guided flat
+        # the guide video is decoded ONCE, by rank 0 (one rank: directly into the filter; several: into the round exchange)
+        guides = iter_frames(video_4k_path, g0, n_guides) if (n_guides and rank == 0) else None
+
+        def next_luma():
+            """rank 0: the next guide frame as a device luma tensor (the BGR frame crosses PCIe once, the luma stays on
+            the device); raises if the decoder ends before the frame count the container promised"""
+            f = next(guides, None)
+            if f is None:
+                raise RuntimeError(f"4K guide video ended early: {video_4k_path}")
+            return self.backend.to_luma(f)
+
+        exchange = None
+        if world > 1 and n_guides:
+            exchange = sharding.GuideRoundExchange((target_height, target_width), self.backend.device)
+
+        def post_round(base):
+            """rank 0 decodes the guide frames of depth frames base .. base+world-1 and posts the round (one collective)"""
+            if base >= n_guides:
+                return False
+            frames = [next_luma() if base + r < n_guides else None for r in range(world)] if rank == 0 else None
+            exchange.post(frames)
+            return True
+
         # this rank's depth maps, decoded a few files ahead on reader threads (PNG inflate is the slowest host step)
         my_depth = prefetch_map(read_png16, [depth_files[i] for i in range(rank, n, world)])
         with PngWriterPool() as writers:                  # 4K 16-bit PNGs: ~80 ms of zlib each, compressed off the main thread
+            posted = post_round(0) if exchange is not None else False
             for base in range(0, n, world):
-                # rank 0 decodes one round of guide frames and broadcasts it; rank r keeps frame base + r
-                round_frames = None
-                if rank == 0:
-                    round_frames = []
-                    for _ in range(world):
-                        f = next(guides, None) if guides is not None else None
-                        # one rank: the luma stays on the device; several: it travels as a host array into the round buffer
-                        luma = None if f is None else self.backend.to_luma(f)
-                        round_frames.append(luma if (luma is None or world == 1) else luma.cpu().numpy())
+                # one round ahead: the collective of round base+world runs on the exchange's side stream while this
+                # round's filter runs on the main stream
+                posted_next = post_round(base + world) if exchange is not None else False
                 i = base + rank
-                guide = sharding.broadcast_guide_round(round_frames, (target_height, target_width), self.backend.device) \
-                    if video_4k_path else None
+                guide = None
+                if exchange is not None:
+                    if posted:
+                        guide = exchange.take()
+                elif i < n_guides:                        # one rank
+                    guide = next_luma()
+                posted = posted_next
                 if i >= n:
                     continue
+                if guide is None:
+                    if i < n_guides:                      # a frame the 4K video holds must never degrade to plain smoothing
+                        raise RuntimeError(f"no guide frame arrived for depth frame {i} (rank {rank})")
+                    guide = self.backend.flat_guide(target_height, target_width)    # beyond the 4K clip: flat guide == plain smoothing upsample
                 d16 = next(my_depth).astype(np.float32)
-                if guide is None:     # no 4K frame for this index: guide with a flat image == plain smoothing upsample
-                    guide = self.backend.flat_guide(target_height, target_width)
                 writers.submit(frames_dir / f"depth4k_{i:06d}.png", self.backend.upscale_u16(d16, guide, self.radius, self.eps))
         sharding.barrier()
 
@@ -180,6 +213,8 @@ def main(argv=None):
                         help='4K frame that matches depth_000000 (alignment offset in frames; default 0)')
     args = parser.parse_args(argv)
     try:
+        from . import sharding
+        sharding.init_process_group()            # no-op for one process; under torchrun: one rank per GPU (sets the device)
         upscaler = SimpleDepthUpscaler(use_nvenc=not args.no_nvenc)
         output_path = upscaler.process_depth_upscaling(depth_dir=args.depth_dir, video_4k_path=args.video_4k,
                                                        output_path=args.output, force_reprocess=args.force,

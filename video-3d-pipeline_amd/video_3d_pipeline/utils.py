@@ -108,21 +108,26 @@ def get_video_info(video_path: str) -> Optional[Dict]:
         return None
 
 
-def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int] = None) -> Iterator[np.ndarray]:
+def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int] = None,
+                stride: int = 1, offset: int = 0) -> Iterator[np.ndarray]:
     """Stream HxWx3 uint8 BGR frames (bounded memory; the reference loads the whole clip into a list,
-    depth.py:160-176)."""
+    depth.py:160-176).  `max_frames` bounds the RANGE [start_frame, start_frame + max_frames); of that range only
+    frames start_frame + offset + k*stride are produced (rank r of a world of w decodes stride = w, offset = r): the
+    others are never converted, and in the indexed containers never read."""
+    if stride < 1 or not 0 <= offset < stride:
+        raise ValueError(f"bad stride/offset {stride}/{offset}")
     kind = _container_kind(video_path)
     if kind in ("npy", "npz"):
         frames, _ = _open_stack(video_path)
         end = frames.shape[0] if max_frames is None else min(frames.shape[0], start_frame + max_frames)
-        for i in range(start_frame, end):
+        for i in range(start_frame + offset, end, stride):
             yield np.ascontiguousarray(frames[i])
         return
     if kind == "pngdir":
         from PIL import Image
         files = _frame_dir_files(Path(video_path))
         end = len(files) if max_frames is None else min(len(files), start_frame + max_frames)
-        for f in files[start_frame:end]:
+        for f in files[start_frame + offset:end:stride]:
             with Image.open(f) as im:
                 rgb = np.asarray(im.convert("RGB"))
             yield np.ascontiguousarray(rgb[..., ::-1])
@@ -138,10 +143,13 @@ def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int]
         cap.set(cv2.CAP_PROP_POS_FRAMES, start_frame)
         n = 0
         while max_frames is None or n < max_frames:
-            ret, frame = cap.read()
-            if not ret:
+            if n % stride == offset:
+                ret, frame = cap.read()
+                if not ret:
+                    break
+                yield frame
+            elif not cap.grab():                  # another rank's frame: advance the decoder, skip retrieval + conversion
                 break
-            yield frame
             n += 1
         cap.release()
         return
@@ -151,7 +159,9 @@ def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int]
         raise RuntimeError(f"Frame extraction failed: no decoder for {video_path}")
     cmd = [ffmpeg, "-v", "error", "-ss", str(start_frame / info["fps"]), "-i", video_path]
     if max_frames is not None:
-        cmd += ["-frames:v", str(max_frames)]
+        cmd += ["-frames:v", str(len(range(offset, max_frames, stride)))]
+    if stride > 1:                                # only this rank's frames leave the decoder
+        cmd += ["-vf", f"select='not(mod(n-{offset},{stride}))'", "-vsync", "0"]
     cmd += ["-f", "rawvideo", "-pix_fmt", "bgr24", "pipe:"]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
     size = info["width"] * info["height"] * 3
