@@ -107,3 +107,29 @@ def test_batch_with_strided_guides(native, oracle):
     for i in range(3):
         want = oracle.guided_upscale(depths[i], guides[i], 8, 1e-3)
         assert _rel_err(got[i], want).max() <= RTOL
+
+
+@pytest.mark.parametrize("Wg,Hg,r,band", [(640, 360, 8, 270), (233, 151, 8, 16), (301, 97, 4, 40), (257, 33, 8, 8), (19, 21, 8, 270),
+                                          (500, 301, 8, 64), (3840, 2160, 8, 270)])
+def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, band):
+    """k_gff (a/b handed stage-1 -> stage-2 waves through LDS, the default) performs the two-sweep kernels' arithmetic in
+    the same order: the outputs are IDENTICAL, for every band height (warm-up rows, ragged last band, bands shorter than
+    the window), odd sizes (scalar stores, half-filled row pairs) and strips that end mid-image; and both meet the oracle"""
+    import torch
+    depth, _ = _case(Wg + band, max(Wg // 2, 8), max(Hg // 2, 8))
+    rng = np.random.default_rng(Wg + 3 * Hg)
+    guide = rng.integers(0, 256, (Hg, Wg), dtype=np.uint8)
+    d, g = native.to_device(depth), native.to_device(guide)
+    try:
+        native.set_option("gf_fused", 0)
+        two = native.guided_upscale(d, g, r, 1e-3)
+        native.set_option("gf_fused", 1)
+        native.set_option("gf_band", band)
+        one = native.guided_upscale(d, g, r, 1e-3)
+    finally:
+        native.set_option("gf_fused", 1)
+        native.set_option("gf_band", 270)
+    assert torch.equal(one, two), f"{int((one != two).sum())} pixels differ, max {float((one - two).abs().max())}"
+    if Wg * Hg <= 700 * 400:
+        want = oracle.guided_upscale(depth, guide, r, 1e-3)
+        assert _rel_err(one.cpu().numpy().astype(np.float64), want).max() <= RTOL

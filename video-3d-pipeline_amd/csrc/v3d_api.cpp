@@ -15,14 +15,14 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.1 (gfx950)"; }
 
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 0 };
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 0 };
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
     if (!key) { v3d_set_error("null key"); return V3D_ERR_ARG; }
-    if (!strcmp(key, "gf_band1") || !strcmp(key, "gf_band2")) {
+    if (!strcmp(key, "gf_band1") || !strcmp(key, "gf_band2") || !strcmp(key, "gf_band")) {
         if (value < 8 || value > 65536) { v3d_set_error("option %s: value %d out of range", key, value); return V3D_ERR_ARG; }
-        (key[7] == '1' ? g_v3d_opt.gf_band1 : g_v3d_opt.gf_band2) = value;
+        (key[7] == '1' ? g_v3d_opt.gf_band1 : key[7] == '2' ? g_v3d_opt.gf_band2 : g_v3d_opt.gf_band) = value;
     } else if (!strcmp(key, "gf_tiled")) g_v3d_opt.gf_tiled = value != 0;
     else if (!strcmp(key, "gf_fused")) g_v3d_opt.gf_fused = value != 0;
     else if (!strcmp(key, "corr_gather")) g_v3d_opt.corr_gather = value != 0;

@@ -16,7 +16,8 @@ void v3d_set_error(const char* fmt, ...);
 struct v3d_lib_options {
     int gf_band1, gf_band2;   // rows per workgroup of the guided sweeps (measured best on 30 x 4K frames)
     int gf_tiled;             // 1: force the LDS-tiled guided kernel for every radius
-    int gf_fused;             // 1: single-launch guided filter (a/b rows kept in an LDS ring), 0: two sweeps through HBM
+    int gf_fused;             // 1: single-launch guided filter (a/b rows handed from stage-1 to stage-2 waves through LDS), 0: two sweeps through HBM
+    int gf_band;              // rows per workgroup of the fused kernel
     int corr_gather;          // 1: fused gather-GEMM correlation (bit-identical, VALU-bound, slower)
 };
 extern v3d_lib_options g_v3d_opt;

@@ -360,6 +360,296 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused form for r in {4, 8}: BOTH box stages in one launch, a/b never touch HBM (the two-sweep form moves
+// 2 x 16 B per 4K pixel through HBM for the f64 a/b planes: 8 of its 11 GB per 30 frames).
+//
+// A 512-thread workgroup owns a strip of 256 columns (224 outputs at r = 8) and marches down a band of rows, two
+// rows per step, with its eight waves SPECIALISED:
+//   waves 0-3 (stage 1)  exactly k_gfm<1>: vertical sliding sums of {g, g*g, p, g*p} in a register ring, horizontal
+//                        window sums through LDS (pixel pairs), the per-pixel algebra -> a, b -- written to an LDS
+//                        row pair instead of HBM;
+//   waves 4-7 (stage 2)  exactly k_gfm<2>, two steps behind: pick the a/b rows up from LDS (one column per thread),
+//                        vertical sliding sums in a second register ring, horizontal window sums through LDS, q -> HBM.
+// Each role keeps ONE ring (<= 128 VGPRs, four waves per SIMD, two workgroups per CU); putting both rings into one
+// thread needs ~180 VGPRs and halves the occupancy of a kernel that lives on its waves covering each other's LDS and
+// barrier stalls.  All hand-offs are double-buffered LDS rows, so a step costs ONE workgroup barrier: in phase p
+// stage 1 runs H1(p-1) then V1(p), stage 2 runs H2(p-3) then V2(p-2).  The arithmetic (operation order included) is
+// that of the two-sweep kernels: results are bit-identical.
+// HBM traffic: guide + depth_lo (x 256/224 strip overlap, + 4r warm-up rows per band) in, q out.
+// Measured on 30 4K frames: 2.15 ms against 2.72 ms for the two sweeps (VALU pipe 61 % busy, LDS pipe 62 %: the kernel is
+// bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
+// skips the count reciprocals away from the border (more spills, 2.26 ms), s_setprio for the stage-1 waves (2.21-2.25 ms).
+// ------------------------------------------------------------------------------------------------
+template <int RR>
+__global__ __launch_bounds__(512, 4) void k_gff(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+                                                const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
+                                                float* __restrict__ out, size_t depth_stride, size_t guide_stride)
+{
+    static_assert(RR % 2 == 0, "pairs must not straddle the strip's halo boundaries");
+    constexpr int R = 2 * RR + 1, NOUT = 256 - 4 * RR;
+    __shared__ __attribute__((aligned(16))) double sV1[2][2][2][256];        // [buffer][row of the pair][sum p | sum g*p][column]
+    __shared__ __attribute__((aligned(16))) int2 sVi[2][2][256];             // [buffer][row][column] {sum g, sum g*g}
+    __shared__ __attribute__((aligned(16))) double sAB[2][2][2][256];        // [buffer][row][a | b][column]   stage 1 -> stage 2
+    __shared__ __attribute__((aligned(16))) double sV2[2][2][2][256];        // [buffer][row][sum a | sum b][column]
+    {   // frame of the batch
+        const size_t f = blockIdx.z, n4 = (size_t)W * H;
+        depth_lo += f * depth_stride; guide += f * guide_stride; out += f * n4;
+    }
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));      // 0: stage 1 (waves 0-3), 1: stage 2 (waves 4-7)
+    const int t = threadIdx.x & 255;
+    const int gx0 = blockIdx.x * NOUT - 2 * RR;                      // image column of strip column 0
+    const int gx = gx0 + t;                                          // vertical phases: this thread's column
+    const int ya = blockIdx.y * band_h, yb = min(ya + band_h, H);
+    const int nrows = (yb - ya) + 4 * RR;                            // input rows ya - 2r .. yb - 1 + 2r
+    const int NS = (nrows + 1) >> 1;                                 // steps (row pairs)
+    const int NP = NS + 3;                                           // phases: the last H2 runs three phases behind the last V1
+    const int hq = t & 127, hgx = gx0 + 2 * hq;                      // horizontal phases: pixel pair (2hq, 2hq+1) of row t >> 7 of the step
+
+    for (int i = threadIdx.x; i < 2 * 2 * 2 * 256; i += 512) (&sAB[0][0][0][0])[i] = 0.0;
+    __syncthreads();
+
+    if (role == 0) {
+        // ================= stage 1: guide + depth -> a, b (k_gfm<1>'s arithmetic) =================
+        const bool col_ok = gx >= 0 && gx < W;
+        const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
+        const bool pair_in = 2 * hq >= RR && 2 * hq < 256 - RR;      // a/b columns of the strip
+        const bool px0 = pair_in && hgx >= 0 && hgx < W, px1 = pair_in && hgx + 1 >= 0 && hgx + 1 < W;
+        int bxa, bxb; double bwx;
+        {
+            const double fx = (gx + 0.5) * sx - 0.5, x0f = floor(fx);
+            bwx = fx - x0f;
+            bxa = min(max((int)x0f, 0), Wlo - 1); bxb = min(max((int)x0f + 1, 0), Wlo - 1);
+        }
+        double r1[R], v0 = 0.0, v1 = 0.0;        // p ring, sum p, sum g*p
+        uint32_t rgw[(R + 3) / 4];               // g ring, one BYTE per row (the guide is 8-bit): 5 registers instead of 17 keep
+        int vg = 0, vgg = 0;                     //   the kernel inside the 128 VGPRs of four waves per SIMD; sum g, sum g*g
+#pragma unroll
+        for (int j = 0; j < R; j++) r1[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < (R + 3) / 4; j++) rgw[j] = 0u;
+        struct RowIn { int g; float a0, a1, b0, b1; bool in; };
+        const int gxc = min(max(gx, 0), W - 1);
+        auto fetch_row = [&](int tt) -> RowIn {        // unconditional loads from clamped addresses (see k_gfm)
+            RowIn q;
+            const int e = ya - 2 * RR + tt;                                      // input row entering the window
+            q.in = col_ok && e >= 0 && e < H && tt < nrows;
+            const size_t o = (size_t)min(max(e, 0), H - 1) * W + gxc;
+            q.g = guide[o];
+            const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy);
+            const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
+            const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
+            q.a0 = ra[bxa]; q.a1 = ra[bxb]; q.b0 = rb[bxa]; q.b1 = rb[bxb];
+            return q;
+        };
+        RowIn nx[2] = { fetch_row(0), fetch_row(1) };
+        for (int p0 = 0; p0 < NP; p0 += R) {
+#pragma unroll
+            for (int sp = 0; sp < R; sp++) {
+                const int p = p0 + sp;
+                if (p < NP) {                                                    // uniform
+                    // (thread constants of the horizontal phase are re-derived per phase, see stage 2: nothing hoisted, nothing spilled)
+                    int tl = t;
+                    asm volatile("" : "+v"(tl));
+                    const int hrow = tl >> 7, hq = tl & 127, hgx = gx0 + 2 * hq;
+                    // ---- H1(p-1): window sums of the row pair V1(p-1) left in LDS -> a, b of two pixels -> sAB ----
+                    const int j = p - 1;
+                    if (j >= RR && j < NS && pair_in) {
+                        const int hb = j & 1;
+                        const int y = ya - 3 * RR + 2 * j + hrow;                // centre row of this window
+                        double ab[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
+                        if (y >= 0 && y < H && px0) {
+                            double fq[2], lq[2], cq[2];
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const v3d_f64x2* d = reinterpret_cast<const v3d_f64x2*>(&sV1[hb][hrow][q][0]) + (hq - RR / 2);
+                                double f = 0.0, l = 0.0, c = 0.0;
+#pragma unroll
+                                for (int ch = 0; ch <= RR; ch += GF_CH) {
+                                    v3d_f64x2 w[GF_CH];
+#pragma unroll
+                                    for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) w[i] = d[ch + i];
+#pragma unroll
+                                    for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) {
+                                        if (ch + i == 0) { f = w[i].x; c = w[i].y; }
+                                        else if (ch + i == RR) { c += w[i].x; l = w[i].y; }
+                                        else { c += w[i].x; c += w[i].y; }
+                                    }
+                                    asm volatile("" : "+v"(c) :: "memory");
+                                }
+                                fq[q] = f; lq[q] = l; cq[q] = c;
+                            }
+                            int g0 = 0, gg0 = 0, gl = 0, ggl = 0, cg = 0, cgg = 0;
+                            {
+                                const int4* gi = reinterpret_cast<const int4*>(&sVi[hb][hrow][0]) + (hq - RR / 2);
+#pragma unroll
+                                for (int ch = 0; ch <= RR; ch += 3) {
+                                    int4 u[3];
+#pragma unroll
+                                    for (int i = 0; i < 3; i++) if (ch + i <= RR) u[i] = gi[ch + i];
+#pragma unroll
+                                    for (int i = 0; i < 3; i++) if (ch + i <= RR) {
+                                        if (ch + i == 0) { g0 = u[i].x; gg0 = u[i].y; cg = u[i].z; cgg = u[i].w; }
+                                        else if (ch + i == RR) { cg += u[i].x; cgg += u[i].y; gl = u[i].z; ggl = u[i].w; }
+                                        else { cg += u[i].x + u[i].z; cgg += u[i].y + u[i].w; }
+                                    }
+                                    asm volatile("" : "+v"(cg), "+v"(cgg) :: "memory");
+                                }
+                            }
+                            const double s0a = cq[0] + fq[0], s0b = cq[0] + lq[0], s1a = cq[1] + fq[1], s1b = cq[1] + lq[1];
+                            const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                            const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
+                            // away from the image border every window holds (2r+1)^2 pixels: a wave whose pixels are all interior
+                            // (the common case) skips both reciprocal refinements (~10 f64 instructions per pixel pair)
+                            const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
+                            const int sga = cg + g0, sgb = cg + gl, sgga = cgg + gg0, sggb = cgg + ggl;
+#pragma unroll
+                            for (int n = 0; n < 2; n++) {
+                                const double inv = n ? invb : inva;
+                                const double mI = (double)(n ? sgb : sga) * (inv * (1.0 / 255.0)), mp = (n ? s0b : s0a) * inv;
+                                const double mII = (double)(n ? sggb : sgga) * (inv * (1.0 / 65025.0)), mIp = (n ? s1b : s1a) * (inv * (1.0 / 255.0));
+                                const double var = fma(-mI, mI, mII), cov = fma(-mI, mp, mIp);
+                                const double a = cov * gf_rcp(var + eps);
+                                ab[n][0] = a; ab[n][1] = fma(-a, mI, mp);
+                            }
+                            if (!px1) { ab[1][0] = 0.0; ab[1][1] = 0.0; }
+                        }
+                        // rows and columns outside the image hand ZERO a/b to stage 2 (its windows count in-image pixels only)
+                        const v3d_f64x2 va2 = { ab[0][0], ab[1][0] }, vb2 = { ab[0][1], ab[1][1] };
+                        *reinterpret_cast<v3d_f64x2*>(&sAB[hb][hrow][0][2 * hq]) = va2;
+                        *reinterpret_cast<v3d_f64x2*>(&sAB[hb][hrow][1][2 * hq]) = vb2;
+                    }
+                    // ---- V1(p): two input rows enter the column's window ----
+                    if (p < NS) {
+                        const int tA = 2 * p;
+                        const RowIn cur[2] = { nx[0], nx[1] };
+                        nx[0] = fetch_row(tA + 2); nx[1] = fetch_row(tA + 3);
+                        const bool emit = p >= RR;                               // uniform
+#pragma unroll
+                        for (int rr = 0; rr < 2; rr++) {
+                            const int slot = (2 * sp + rr) % R;                  // compile-time ring slot
+                            int gn = 0; double pn = 0.0;
+                            if (cur[rr].in) {
+                                gn = cur[rr].g;
+                                const int e = ya - 2 * RR + tA + rr;
+                                const double fy = (e + 0.5) * sy - 0.5, wy = fy - floor(fy);
+                                const double a0 = (double)cur[rr].a0, b0 = (double)cur[rr].b0;
+                                const double top = fma(bwx, (double)cur[rr].a1 - a0, a0);
+                                const double bot = fma(bwx, (double)cur[rr].b1 - b0, b0);
+                                pn = fma(wy, bot - top, top);
+                            }
+                            const int go = (int)((rgw[slot >> 2] >> (8 * (slot & 3))) & 0xFFu); const double po = r1[slot];
+                            rgw[slot >> 2] = (rgw[slot >> 2] & ~(0xFFu << (8 * (slot & 3)))) | ((uint32_t)gn << (8 * (slot & 3)));
+                            r1[slot] = pn;
+                            vg += gn - go; vgg += gn * gn - go * go;
+                            v0 += pn - po; v1 = fma((double)gn, pn, fma(-(double)go, po, v1));
+                            if (emit) {
+                                sV1[p & 1][rr][0][t] = v0; sV1[p & 1][rr][1][t] = v1;
+                                sVi[p & 1][rr][t] = make_int2(vg, vgg);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        // ================= stage 2: a, b -> q (k_gfm<2>'s arithmetic) =================
+        const bool pair_out = 2 * hq >= 2 * RR && 2 * hq < 256 - 2 * RR;           // output columns of the strip
+        const bool px0 = pair_out && hgx < W, px1 = pair_out && hgx + 1 < W;
+        const bool vec_ok = px1 && (W & 1) == 0;
+        double r0[R], r1[R], va = 0.0, vb = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; j++) { r0[j] = 0.0; r1[j] = 0.0; }
+        for (int p0 = 0; p0 < NP; p0 += R) {
+#pragma unroll
+            for (int sp = 0; sp < R; sp++) {
+                const int p = p0 + sp;
+                if (p < NP) {                                                    // uniform
+                    // Thread constants are RE-DERIVED from the thread index in every phase (the asm makes the value opaque, so
+                    // nothing derived from it can be hoisted out of the loop): with two 34-register rings this role has no
+                    // room to keep LDS addresses, window widths and column indices live across phases -- hoisted, they spill.
+                    int tl = t;
+                    asm volatile("" : "+v"(tl));
+                    const int hrow = tl >> 7, hq = tl & 127, hgx = gx0 + 2 * hq;
+                    // ---- H2(p-3): window sums of the a/b row pair -> q of two pixels ----
+                    {
+                        const int j = p - 3;
+                        const int y = ya - 4 * RR + 2 * j + hrow;
+                        if (j >= 2 * RR && j < NS && px0 && y < yb) {
+                            const int hb = j & 1;
+                            // one plane at a time, window sums folded at once: four live values per plane (stage 2 sits at the
+                            // 128-VGPR edge with its two 34-register rings)
+                            double wa[2], wb[2];
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const v3d_f64x2* d = reinterpret_cast<const v3d_f64x2*>(&sV2[hb][hrow][q][0]) + (hq - RR / 2);
+                                double f = 0.0, l = 0.0, c = 0.0;
+#pragma unroll
+                                for (int ch = 0; ch <= RR; ch += 2) {
+                                    v3d_f64x2 w[2];
+#pragma unroll
+                                    for (int i = 0; i < 2; i++) if (ch + i <= RR) w[i] = d[ch + i];
+#pragma unroll
+                                    for (int i = 0; i < 2; i++) if (ch + i <= RR) {
+                                        if (ch + i == 0) { f = w[i].x; c = w[i].y; }
+                                        else if (ch + i == RR) { c += w[i].x; l = w[i].y; }
+                                        else { c += w[i].x; c += w[i].y; }
+                                    }
+                                    asm volatile("" : "+v"(c) :: "memory");
+                                }
+                                wa[q] = c + f; wb[q] = c + l;
+                                asm volatile("" : "+v"(wa[q]), "+v"(wb[q]) :: "memory");
+                            }
+                            const double s0a = wa[0], s0b = wb[0], s1a = wa[1], s1b = wb[1];
+                            const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                            const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
+                            const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
+                            const size_t o = (size_t)y * W + hgx;
+                            const double Ia = (double)guide[o] * (1.0 / 255.0);
+                            const double Ib = px1 ? (double)guide[o + 1] * (1.0 / 255.0) : 0.0;
+                            const float qa = (float)((s0a * inva) * Ia + (s1a * inva)), qb = (float)((s0b * invb) * Ib + (s1b * invb));
+                            if (vec_ok) {
+                                v3d_f32x2 vq = { qa, qb };
+                                __builtin_nontemporal_store(vq, reinterpret_cast<v3d_f32x2*>(out + o));
+                            } else {
+                                out[o] = qa;
+                                if (px1) out[o + 1] = qb;
+                            }
+                        }
+                    }
+                    // ---- V2(p-2): the a/b row pair H1(p-2) left in LDS enters the column's window ----
+                    {
+                        const int j = p - 2;
+                        if (j >= RR && j < NS) {
+                            const bool emit = j >= 2 * RR;                       // uniform
+#pragma unroll
+                            for (int rr = 0; rr < 2; rr++) {
+                                const int slot = (2 * sp + rr) % R;              // compile-time ring slot
+                                const double n0 = sAB[j & 1][rr][0][tl], n1 = sAB[j & 1][rr][1][tl];
+                                const double o0 = r0[slot], o1 = r1[slot];
+                                r0[slot] = n0; r1[slot] = n1;
+                                va += n0 - o0; vb += n1 - o1;
+                                if (emit) { sV2[j & 1][rr][0][tl] = va; sV2[j & 1][rr][1][tl] = vb; }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+template <int RR>
+static void launch_gff(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
+                       float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
+{
+    const int band = g_v3d_opt.gf_band;
+    const dim3 grid(v3d_cdiv(W, 256 - 4 * RR), v3d_cdiv(H, band), n);
+    hipLaunchKernelGGL((k_gff<RR>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+}
+
 template <int RR>
 static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        double* A, double* B, float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
@@ -398,6 +688,12 @@ extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo,
     hipStream_t st = (hipStream_t)stream;
     double* A = reinterpret_cast<double*>(ws);
     double* B = A + (size_t)W * H;
+    if (!g_v3d_opt.gf_tiled && g_v3d_opt.gf_fused && (r == 4 || r == 8)) {
+        if (r == 4) launch_gff<4>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, out, n, depth_stride, guide_stride, st);
+        else launch_gff<8>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, out, n, depth_stride, guide_stride, st);
+        V3D_LAUNCH_CHECK();
+        return V3D_OK;
+    }
     if (!g_v3d_opt.gf_tiled && (r == 4 || r == 8)) {     // larger rings spill: r = 16 takes the tiled kernel
         if (r == 4) launch_gfm<4>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
         else launch_gfm<8>(depth_lo, Wlo, Hlo, guide, W, H, (double)eps, A, B, out, n, depth_stride, guide_stride, st);
