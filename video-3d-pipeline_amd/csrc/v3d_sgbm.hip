@@ -605,7 +605,15 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     for (int blk = nblk - 1; blk >= 0; blk--) {
         const int x0 = blk * K;
         // (prefetching the next block's C/S into a second register set was tried: 182 VGPRs halve the
-        //  occupancy and the kernel gets slower, 1.84 -> 2.07 ms per 8 frames; other waves cover the latency)
+        //  occupancy and the kernel gets slower, 1.84 -> 2.07 ms per 8 frames; other waves cover the latency.
+        //  Round 2, 30 frames, same-box A/B: issuing the next block's loads before this block's WTA tail, folding the
+        //  recomputed left path into S at once (no L0 array), prefetching C one further block ahead (all 153 VGPRs, 3
+        //  waves per SIMD), double- and triple-buffering phase 1's C blocks (119-122 VGPRs) -- every one of them lands on
+        //  the same 4.91-4.95 ms as this form; forced to 128 VGPRs the prefetching forms spill and take 6.6-7.1 ms.
+        //  Experiment builds that drop work: no WTA tail 4.57 ms, no phase 1 3.29 ms, neither 2.69 ms (= 5.9 TB/s for
+        //  phase 2's C + S + checkpoints).  So phase 2 without the WTA streams at the box's read ceiling, phase 1 adds
+        //  its 8.2 GB at ~4.5 TB/s and the WTA tail 0.4-0.6 ms that no amount of load scheduling hides: the kernel is
+        //  bound by the memory system (24.5 GB at 5.0 TB/s, VALU 56 % busy), not by latency exposure or occupancy.)
         Vec cvv[K], svv[K];
 #pragma unroll
         for (int j = 0; j < K; j++) {
