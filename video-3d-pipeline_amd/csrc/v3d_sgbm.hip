@@ -985,13 +985,17 @@ __global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restric
 // a-8: filterSpeckles as run-based connected-component labelling.  Components are the 4-connected
 // sets of valid pixels joined where |a - b| <= maxDiff; components of at most maxSpeckleSize pixels
 // are invalidated.  (1) every row is cut into horizontal runs by a block-wide scan (no atomics);
-// a run is named by the index of its first pixel and carries its length.  (2) runs of adjacent
-// rows are joined with a lock-free union-find, one union per overlapping run pair instead of one
-// per pixel.  (3) run lengths are added at the roots, (4) small components are erased.
+// a run is named by the index of its first pixel, carries its length, and is appended to its row's
+// RUN LIST.  (2) runs of adjacent rows are joined with a lock-free union-find, one union per overlapping
+// run pair instead of one per pixel.  (3) run lengths are added at the roots, (4) small components are
+// erased -- (3) and (4) walk the run lists (tens of runs per row), not the pixels.
 // The outcome is schedule-independent: union-find yields the same partition in any order, and
 // sizes are only ever compared against the threshold.
-//   lab  [n]: run start for non-start pixels (constant); parent pointer for run starts; -1 invalid
-//   rlen [n]: run length at run starts, 0 elsewhere;  csz [n]: component size, accumulated at roots
+//   lab  [n]: run start for non-start pixels (constant); parent pointer for run starts; -1 invalid   (dense)
+//   runs [n]: per row, the run starts of that row in x order, ended by -1 if the row has fewer than W runs
+//   csz  [n]: at run starts only: the run's length, and at a root the running size of its component
+// Dense traffic per pixel: img read + lab write (k_ccl_runs), two img rows read (k_ccl_vmerge); the round-1 form also
+// wrote and re-read dense length / size planes and re-read lab per pixel (~40 B per pixel, 0.81 ms per 30 frames).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ccl_ld(const int* L, int i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ccl_find(const int* L, int i)
@@ -1026,17 +1030,17 @@ __device__ __forceinline__ void ccl_union(int* L, int a, int b)
 }
 __device__ __forceinline__ bool ccl_conn(int a, int b, int newVal, int maxDiff) { return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
 
-// one block per image row; pixels are taken in chunks of 256 (thread t <-> pixel 256*j + t: coalesced),
-// the "latest run start at or before x" is an inclusive max-scan: DPP/shuffle inside a wave, 4 wave
-// totals through LDS, and a carry from chunk to chunk.
+// one block per image row; pixels are taken in chunks of 256 (thread t <-> pixel 256*j + t: coalesced).
+// "Latest run start at or before x" is an inclusive max-scan, "run starts before x" an exclusive count: DPP/shuffle
+// and ballot inside a wave, 4 wave totals through LDS, and a carry from chunk to chunk.
 __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff,
-                                                  int* __restrict__ lab, int* __restrict__ rlen, int* __restrict__ csz)
+                                                  int* __restrict__ lab, int* __restrict__ runs, int* __restrict__ csz)
 {
-    __shared__ int sWave[2][4];
+    __shared__ int sWave[2][4], sCnt[2][4];
     const int y = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const size_t fo = (size_t)blockIdx.z * W * H + (size_t)y * W;
     const int16_t* row = img + fo;
-    int carry = -1;
+    int carry = -1, nrun = 0;
     for (int x0 = 0, j = 0; x0 < W; x0 += 256, j++) {
         const int x = x0 + t;
         const bool in = x < W;
@@ -1051,23 +1055,26 @@ __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ im
             const int o = __shfl_up(m, off);
             if (lane >= off) m = max(m, o);
         }
-        if (lane == 63) sWave[j & 1][wv] = m;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(start);
+        const int before = __popcll(sm & ((1ull << lane) - 1ull));       // run starts of this wave before this lane
+        if (lane == 63) { sWave[j & 1][wv] = m; sCnt[j & 1][wv] = __popcll(sm); }
         __syncthreads();
-        int pre = carry;
+        int pre = carry, pos = nrun;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const int tot = sWave[j & 1][w]; if (w < wv) pre = max(pre, tot); carry = max(carry, tot); }
+        for (int w = 0; w < 4; w++) {
+            const int tot = sWave[j & 1][w], cn = sCnt[j & 1][w];
+            if (w < wv) { pre = max(pre, tot); pos += cn; }
+            carry = max(carry, tot); nrun += cn;
+        }
         const int cur = max(m, pre);                           // run start of pixel x (if valid)
         if (in) {
             const size_t i = fo + x;
-            csz[i] = 0;
-            if (!valid) { lab[i] = -1; rlen[i] = 0; }
-            else {
-                lab[i] = y * W + cur;
-                if (!start) rlen[i] = 0;
-                if (!ccl_conn(v, nv, newVal, maxDiff)) rlen[fo + cur] = x - cur + 1;     // I am the run's last pixel
-            }
+            lab[i] = valid ? y * W + cur : -1;
+            if (start) runs[fo + pos + before] = y * W + x;
+            if (valid && !ccl_conn(v, nv, newVal, maxDiff)) csz[fo + cur] = x - cur + 1;     // I am the run's last pixel: its length
         }
     }
+    if (t == 0 && nrun < W) runs[fo + nrun] = -1;              // end of the row's run list
 }
 
 // Two launches: LEVEL 0 joins the row pairs inside bands of VM_BAND rows (trees at most VM_BAND deep), LEVEL 1 the
@@ -1092,42 +1099,70 @@ __global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ 
     ccl_union(L, L[i], L[i + W]);
 }
 
-__global__ __launch_bounds__(256) void k_ccl_count(int n, int maxSize, int* __restrict__ lab, const int* __restrict__ rlen, int* __restrict__ csz)
+// (3) and (4): one WAVE per image row walks that row's run list, 64 runs per step.
+// count: every non-root run adds its length to its root (a root's own length is already there).  Only "<= maxSize or
+// not" matters: stop adding once the root is known to be large.
+__global__ __launch_bounds__(256) void k_ccl_count(int W, int H, int maxSize, int* __restrict__ lab, const int* __restrict__ runs, int* __restrict__ csz)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t fo = (size_t)blockIdx.z * n;
-    const int len = rlen[fo + i];
-    if (len <= 0) return;                                      // run starts only
-    int* L = lab + fo;
-    const int r = ccl_find(L, i);
-    if (r != i) L[i] = r;                                      // path compression (the forest is final here)
-    // only "<= maxSize or not" matters: stop adding once the root is known to be large
-    if (__hip_atomic_load(csz + fo + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(csz + fo + r, len);
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (y >= H) return;                                        // wave-uniform
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    int* L = lab + fo; int* C = csz + fo;
+    const int* rl = runs + fo + (size_t)y * W;
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        const int k = k0 + lane;
+        const int s = k < W ? rl[k] : -1;
+        // entries behind the end marker are stale: a lane counts only if every entry before it in this step is a run
+        const unsigned long long endm = __builtin_amdgcn_ballot_w64(s < 0);
+        const int first_end = endm ? __builtin_ctzll(endm) : 64;
+        if (lane < first_end) {
+            const int r = ccl_find(L, s);
+            if (r != s) {
+                L[s] = r;                                      // path compression (the forest is final here)
+                if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(C + r, C[s]);
+            }
+        }
+        if (first_end < 64) break;                             // wave-uniform
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ csz)
+// apply: a run whose component is small is overwritten pixel by pixel (at most maxSize of them: the loop is short and rare)
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* __restrict__ img, int W, int H, int newVal, int maxSize,
+                                                   const int* __restrict__ lab, const int* __restrict__ runs, const int* __restrict__ csz)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t fo = (size_t)blockIdx.z * n;
-    const int l = lab[fo + i];
-    if (l < 0) return;
-    const int r = ccl_find(lab + fo, l);
-    if (csz[fo + r] <= maxSize) img[fo + i] = (int16_t)newVal;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (y >= H) return;                                        // wave-uniform
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    const int* L = lab + fo;
+    const int* rl = runs + fo + (size_t)y * W;
+    const int row_end = (y + 1) * W;
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        const int k = k0 + lane;
+        const int s = k < W ? rl[k] : -1;
+        const unsigned long long endm = __builtin_amdgcn_ballot_w64(s < 0);
+        const int first_end = endm ? __builtin_ctzll(endm) : 64;
+        if (lane < first_end) {
+            const int r = ccl_find(L, s);
+            if (csz[fo + r] <= maxSize) {
+                img[fo + s] = (int16_t)newVal;
+                for (int i = s + 1; i < row_end && L[i] == s; i++) img[fo + i] = (int16_t)newVal;    // non-start pixels carry their run's start
+            }
+        }
+        if (first_end < 64) break;                             // wave-uniform
+    }
 }
 
-// the four launches; ws = 3 * n_pixels * frames int32
+// the five launches; ws = 3 * n_pixels * frames int32
 static int launch_speckles(int16_t* img, int W, int H, int frames, int newVal, int maxSize, int maxDiff, int32_t* ws, hipStream_t st)
 {
     const int px = W * H;
-    int* lab = ws; int* rlen = ws + (size_t)px * frames; int* csz = ws + (size_t)px * frames * 2;
-    hipLaunchKernelGGL(k_ccl_runs, dim3(H, 1, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab, rlen, csz);
+    int* lab = ws; int* runs = ws + (size_t)px * frames; int* csz = ws + (size_t)px * frames * 2;
+    hipLaunchKernelGGL(k_ccl_runs, dim3(H, 1, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab, runs, csz);
     // rows y with (y % VM_BAND) != VM_BAND-1 first (blockIdx.y enumerates them), then the band boundaries
     hipLaunchKernelGGL(k_ccl_vmerge<0>, dim3(v3d_cdiv(W, 256), H - H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
     if (H / VM_BAND > 0) hipLaunchKernelGGL(k_ccl_vmerge<1>, dim3(v3d_cdiv(W, 256), H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
-    hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, px, maxSize, lab, rlen, csz);
-    hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(px, 256), 1, frames), dim3(256), 0, st, img, px, newVal, maxSize, lab, csz);
+    hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(H, 4), 1, frames), dim3(256), 0, st, W, H, maxSize, lab, runs, csz);
+    hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(H, 4), 1, frames), dim3(256), 0, st, img, W, H, newVal, maxSize, lab, runs, csz);
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
