@@ -9,4 +9,7 @@ for path in sys.argv[1:]:
             per_dispatch[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, _, c), v in per_dispatch.items(): acc[k][c].append(v)
     for k in sorted(acc):
-        print(f"{k:28s} " + " ".join(f"{c.replace('SQ_', '')}={sum(v) / len(v) / 1e6:,.1f}M" for c, v in sorted(acc[k].items())))
+        def fmt(c, v):
+            m = sum(v) / len(v)
+            return f"{c.replace('SQ_', '')}={m / 1e6:,.1f}M" if m >= 1e6 else f"{c.replace('SQ_', '')}={m:,.0f}"
+        print(f"{k:28s} " + " ".join(fmt(c, v) for c, v in sorted(acc[k].items())))
