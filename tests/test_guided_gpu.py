@@ -109,9 +109,10 @@ def test_batch_with_strided_guides(native, oracle):
         assert _rel_err(got[i], want).max() <= RTOL
 
 
+@pytest.mark.parametrize("cols", [256, 512])
 @pytest.mark.parametrize("Wg,Hg,r,band", [(640, 360, 8, 270), (233, 151, 8, 16), (301, 97, 4, 40), (257, 33, 8, 8), (19, 21, 8, 270),
                                           (500, 301, 8, 64), (3840, 2160, 8, 270)])
-def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, band):
+def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, band, cols):
     """k_gff (a/b handed stage-1 -> stage-2 waves through LDS, the default) performs the two-sweep kernels' arithmetic in
     the same order: the outputs are IDENTICAL, for every band height (warm-up rows, ragged last band, bands shorter than
     the window), odd sizes (scalar stores, half-filled row pairs) and strips that end mid-image; and both meet the oracle"""
@@ -125,10 +126,12 @@ def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, b
         two = native.guided_upscale(d, g, r, 1e-3)
         native.set_option("gf_fused", 1)
         native.set_option("gf_band", band)
+        native.set_option("gf_cols", cols)                     # 512-column strips: 16 waves, one workgroup per CU
         one = native.guided_upscale(d, g, r, 1e-3)
     finally:
         native.set_option("gf_fused", 1)
         native.set_option("gf_band", 270)
+        native.set_option("gf_cols", 256)
     assert torch.equal(one, two), f"{int((one != two).sum())} pixels differ, max {float((one - two).abs().max())}"
     if Wg * Hg <= 700 * 400:
         want = oracle.guided_upscale(depth, guide, r, 1e-3)

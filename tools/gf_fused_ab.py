@@ -21,12 +21,12 @@ ref = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device="cuda"); out = 
 N.set_option("gf_fused", 0)
 t0 = timeit(lambda: N.guided_upscale_batch(depth, guide, 8, 1e-3, ref)); print(f"two sweeps      : {t0:.3f} ms / {B} frames")
 N.set_option("gf_fused", 1)
-for band in [int(x) for x in os.environ.get("BANDS", "135,180,270,360,540,1080,2160").split(",")]:
-    N.set_option("gf_band", band); out.zero_()
+for cols, band in [(c, int(x)) for c in (256, 512) for x in os.environ.get("BANDS", "135,180,270,360,540,1080,2160").split(",")]:
+    N.set_option("gf_cols", cols); N.set_option("gf_band", band); out.zero_()
     t = timeit(lambda: N.guided_upscale_batch(depth, guide, 8, 1e-3, out))
     rel = ((out.double() - ref.double()).abs() / ref.double().abs().clamp_min(1e-6 * float(ref.max()))).max().item()
-    print(f"fused, band {band:4d}: {t:.3f} ms / {B} frames   identical to two-sweep: {bool(torch.equal(out, ref))}  max rel diff {rel:.2e}")
+    print(f"fused, {cols} cols, band {band:4d}: {t:.3f} ms / {B} frames   identical to two-sweep: {bool(torch.equal(out, ref))}  max rel diff {rel:.2e}")
 for r in (4,):
     N.set_option("gf_fused", 0); N.guided_upscale_batch(depth[:2], guide[:2], r, 1e-3, ref[:2])
-    N.set_option("gf_fused", 1); N.set_option("gf_band", 270); N.guided_upscale_batch(depth[:2], guide[:2], r, 1e-3, out[:2])
+    N.set_option("gf_fused", 1); N.set_option("gf_cols", 256); N.set_option("gf_band", 270); N.guided_upscale_batch(depth[:2], guide[:2], r, 1e-3, out[:2])
     print(f"r = {r}: identical {bool(torch.equal(out[:2], ref[:2]))}")

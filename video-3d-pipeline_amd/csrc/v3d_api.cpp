@@ -15,7 +15,7 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.1 (gfx950)"; }
 
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 0 };
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 256, 0 };
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
@@ -25,6 +25,10 @@ extern "C" int v3d_set_option(const char* key, int value)
         (key[7] == '1' ? g_v3d_opt.gf_band1 : key[7] == '2' ? g_v3d_opt.gf_band2 : g_v3d_opt.gf_band) = value;
     } else if (!strcmp(key, "gf_tiled")) g_v3d_opt.gf_tiled = value != 0;
     else if (!strcmp(key, "gf_fused")) g_v3d_opt.gf_fused = value != 0;
+    else if (!strcmp(key, "gf_cols")) {
+        if (value != 256 && value != 512) { v3d_set_error("option gf_cols: 256 or 512"); return V3D_ERR_ARG; }
+        g_v3d_opt.gf_cols = value;
+    }
     else if (!strcmp(key, "corr_gather")) g_v3d_opt.corr_gather = value != 0;
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
     return V3D_OK;

@@ -381,39 +381,40 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
 // bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
 // skips the count reciprocals away from the border (more spills, 2.26 ms), s_setprio for the stage-1 waves (2.21-2.25 ms).
 // ------------------------------------------------------------------------------------------------
-template <int RR>
-__global__ __launch_bounds__(512, 4) void k_gff(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+template <int RR, int COLS>
+__global__ __launch_bounds__(2 * COLS, 4) void k_gff(const float* __restrict__ depth_lo, int Wlo, int Hlo,
                                                 const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
                                                 float* __restrict__ out, size_t depth_stride, size_t guide_stride)
 {
     static_assert(RR % 2 == 0, "pairs must not straddle the strip's halo boundaries");
-    constexpr int R = 2 * RR + 1, NOUT = 256 - 4 * RR;
-    __shared__ __attribute__((aligned(16))) double sV1[2][2][2][256];        // [buffer][row of the pair][sum p | sum g*p][column]
-    __shared__ __attribute__((aligned(16))) int2 sVi[2][2][256];             // [buffer][row][column] {sum g, sum g*g}
-    __shared__ __attribute__((aligned(16))) double sAB[2][2][2][256];        // [buffer][row][a | b][column]   stage 1 -> stage 2
-    __shared__ __attribute__((aligned(16))) double sV2[2][2][2][256];        // [buffer][row][sum a | sum b][column]
+    constexpr int R = 2 * RR + 1, NOUT = COLS - 4 * RR, HP = COLS / 2;      // HP pixel pairs per row
+    static_assert(COLS == 256 || COLS == 512, "strip width");
+    __shared__ __attribute__((aligned(16))) double sV1[2][2][2][COLS];        // [buffer][row of the pair][sum p | sum g*p][column]
+    __shared__ __attribute__((aligned(16))) int2 sVi[2][2][COLS];             // [buffer][row][column] {sum g, sum g*g}
+    __shared__ __attribute__((aligned(16))) double sAB[2][2][2][COLS];        // [buffer][row][a | b][column]   stage 1 -> stage 2
+    __shared__ __attribute__((aligned(16))) double sV2[2][2][2][COLS];        // [buffer][row][sum a | sum b][column]
     {   // frame of the batch
         const size_t f = blockIdx.z, n4 = (size_t)W * H;
         depth_lo += f * depth_stride; guide += f * guide_stride; out += f * n4;
     }
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));      // 0: stage 1 (waves 0-3), 1: stage 2 (waves 4-7)
-    const int t = threadIdx.x & 255;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / COLS));    // 0: stage 1 (first half of the waves), 1: stage 2
+    const int t = threadIdx.x % COLS;
     const int gx0 = blockIdx.x * NOUT - 2 * RR;                      // image column of strip column 0
     const int gx = gx0 + t;                                          // vertical phases: this thread's column
     const int ya = blockIdx.y * band_h, yb = min(ya + band_h, H);
     const int nrows = (yb - ya) + 4 * RR;                            // input rows ya - 2r .. yb - 1 + 2r
     const int NS = (nrows + 1) >> 1;                                 // steps (row pairs)
     const int NP = NS + 3;                                           // phases: the last H2 runs three phases behind the last V1
-    const int hq = t & 127, hgx = gx0 + 2 * hq;                      // horizontal phases: pixel pair (2hq, 2hq+1) of row t >> 7 of the step
+    const int hq = t % HP, hgx = gx0 + 2 * hq;                       // horizontal phases: pixel pair (2hq, 2hq+1) of row t / HP of the step
 
-    for (int i = threadIdx.x; i < 2 * 2 * 2 * 256; i += 512) (&sAB[0][0][0][0])[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * 2 * 2 * COLS; i += 2 * COLS) (&sAB[0][0][0][0])[i] = 0.0;
     __syncthreads();
 
     if (role == 0) {
         // ================= stage 1: guide + depth -> a, b (k_gfm<1>'s arithmetic) =================
         const bool col_ok = gx >= 0 && gx < W;
         const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
-        const bool pair_in = 2 * hq >= RR && 2 * hq < 256 - RR;      // a/b columns of the strip
+        const bool pair_in = 2 * hq >= RR && 2 * hq < COLS - RR;      // a/b columns of the strip
         const bool px0 = pair_in && hgx >= 0 && hgx < W, px1 = pair_in && hgx + 1 >= 0 && hgx + 1 < W;
         int bxa, bxb; double bwx;
         {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(512, 4) void k_gff(const float* __restrict__ depth_
                     // (thread constants of the horizontal phase are re-derived per phase, see stage 2: nothing hoisted, nothing spilled)
                     int tl = t;
                     asm volatile("" : "+v"(tl));
-                    const int hrow = tl >> 7, hq = tl & 127, hgx = gx0 + 2 * hq;
+                    const int hrow = tl / HP, hq = tl % HP, hgx = gx0 + 2 * hq;
                     // ---- H1(p-1): window sums of the row pair V1(p-1) left in LDS -> a, b of two pixels -> sAB ----
                     const int j = p - 1;
                     if (j >= RR && j < NS && pair_in) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(512, 4) void k_gff(const float* __restrict__ depth_
         }
     } else {
         // ================= stage 2: a, b -> q (k_gfm<2>'s arithmetic) =================
-        const bool pair_out = 2 * hq >= 2 * RR && 2 * hq < 256 - 2 * RR;           // output columns of the strip
+        const bool pair_out = 2 * hq >= 2 * RR && 2 * hq < COLS - 2 * RR;           // output columns of the strip
         const bool px0 = pair_out && hgx < W, px1 = pair_out && hgx + 1 < W;
         const bool vec_ok = px1 && (W & 1) == 0;
         double r0[R], r1[R], va = 0.0, vb = 0.0;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(512, 4) void k_gff(const float* __restrict__ depth_
                     // room to keep LDS addresses, window widths and column indices live across phases -- hoisted, they spill.
                     int tl = t;
                     asm volatile("" : "+v"(tl));
-                    const int hrow = tl >> 7, hq = tl & 127, hgx = gx0 + 2 * hq;
+                    const int hrow = tl / HP, hq = tl % HP, hgx = gx0 + 2 * hq;
                     // ---- H2(p-3): window sums of the a/b row pair -> q of two pixels ----
                     {
                         const int j = p - 3;
@@ -646,8 +647,13 @@ static void launch_gff(const float* depth_lo, int Wlo, int Hlo, const uint8_t* g
                        float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
     const int band = g_v3d_opt.gf_band;
+    if (g_v3d_opt.gf_cols == 512) {        // 512-column strips, 16 waves, one workgroup per CU: half the strip-halo recompute
+        const dim3 grid(v3d_cdiv(W, 512 - 4 * RR), v3d_cdiv(H, band), n);
+        hipLaunchKernelGGL((k_gff<RR, 512>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+        return;
+    }
     const dim3 grid(v3d_cdiv(W, 256 - 4 * RR), v3d_cdiv(H, band), n);
-    hipLaunchKernelGGL((k_gff<RR>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gff<RR, 256>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
 }
 
 template <int RR>
