@@ -65,3 +65,24 @@ def test_sbs_to_gray_batch_equals_single(native, oracle):
     for i in range(3):
         wl, wr = oracle.sbs_to_gray(sbs[i], True)
         assert not mismatch_report(L[i].cpu().numpy(), wl, f"left[{i}]") and not mismatch_report(R[i].cpu().numpy(), wr, f"right[{i}]")
+
+
+@pytest.mark.parametrize("off", [1, 2, 3])
+@pytest.mark.parametrize("unsqueeze", [True, False])
+def test_sbs_from_an_unaligned_base_pointer(native, oracle, off, unsqueeze):
+    """the C API takes any pointer.  A frame that starts `off` bytes into an allocation (first byte of the
+    buffer = first byte the kernel may touch) must neither read before the buffer nor change a single output sample."""
+    import torch
+    from video_3d_pipeline import synthetic as syn
+    sbs = syn.sbs_frame(538, 37, 5)                          # odd row count, W*3 = 1614 bytes per row: rows land on every alignment
+    H, W, _ = sbs.shape
+    buf = torch.zeros(off + sbs.size, dtype=torch.uint8, device="cuda")
+    buf[off:] = native.to_device(sbs).reshape(-1)
+    view = buf[off:].view(H, W, 3)
+    assert view.data_ptr() % 4 == off and view.is_contiguous()
+    gl, gr = native.sbs_to_gray(view, unsqueeze)
+    wl, wr = oracle.sbs_to_gray(sbs, unsqueeze)
+    assert np.array_equal(gl.cpu().numpy(), wl) and np.array_equal(gr.cpu().numpy(), wr)
+    bl, br = native.split_sbs(view, unsqueeze)
+    ol, orr = oracle.split_sbs(sbs, unsqueeze)
+    assert np.array_equal(bl.cpu().numpy(), ol) and np.array_equal(br.cpu().numpy(), orr)

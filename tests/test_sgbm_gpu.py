@@ -383,3 +383,25 @@ def test_reserved_cus_shrink_the_lockstep_launch(native, oracle):
     m.close()
     for i in range(n):
         assert not mismatch_report(got[i], oracle.sgbm_compute(*pairs[i]), f"frame {i}")
+
+
+@pytest.mark.parametrize("W,H", [(300, 40), (64, 9), (1, 5), (257, 1), (640, 33)])
+def test_speckle_run_lists_extremes(native, oracle, W, H):
+    """the run-list CCL at its corners: every pixel its own run (a full run list without end marker, > 64 runs per row
+    -> several steps of the per-row walkers), one run per row, single-column / single-row images, runs of exactly the
+    threshold length, and random mixtures with a tight maxDiff"""
+    rng = np.random.default_rng(W * 31 + H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    cases = {
+        "checkerboard": np.where((yy + xx) % 2 == 0, 0, 8000).astype(np.int16),            # no two neighbours connect: all size 1
+        "rows": (yy * 16).astype(np.int16) * np.ones((1, W), np.int16),                    # one run per row, all joined vertically
+        "columns": np.where(xx % 2 == 0, 160, 9000).astype(np.int16),                      # W runs per row, joined vertically: size H each
+        "random": (rng.integers(0, 6, (H, W)) * 700).astype(np.int16),
+        "sparse": np.where(rng.random((H, W)) < 0.6, -16, (rng.integers(0, 4, (H, W)) * 300)).astype(np.int16),
+    }
+    for name, img in cases.items():
+        for max_size, max_diff in ((100, 512), (H, 100), (3, 1)):
+            got = native.filter_speckles(_dev(native, img), -16, max_size, max_diff).cpu().numpy()
+            want = oracle.filter_speckles(img, -16, max_size, max_diff)
+            assert not mismatch_report(got, want, f"{name} {W}x{H} size<={max_size} diff<={max_diff}"), \
+                mismatch_report(got, want, f"{name} {W}x{H} size<={max_size} diff<={max_diff}")
