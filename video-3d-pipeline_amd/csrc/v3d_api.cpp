@@ -13,7 +13,7 @@ void v3d_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* v3d_last_error(void) { return g_err; }
-extern "C" const char* v3d_version(void) { return "libv3d_hip 0.1 (gfx950)"; }
+extern "C" const char* v3d_version(void) { return "libv3d_hip 0.2 (gfx950)"; }
 
 v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 256, 0 };
 
