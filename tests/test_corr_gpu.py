@@ -64,3 +64,21 @@ def test_fused_gather_gemm_is_bit_identical(native):
         finally:
             native.set_option("corr_gather", 0)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w,G", [(10, 40, 2), (7, 64, 4), (5, 130, 4), (3, 17, 1), (270, 480, 4)])
+def test_lds_gather_gemm_equals_the_two_kernel_form(native, h, w, G):
+    """k_corr_fused0 (1x9 default: the block's 72 warped positions staged once in LDS, outputs transposed through LDS) gives the
+    bits of k_corr_warp + k_corr: ragged last block, rows narrower than a block, the full 270x480x256 shape"""
+    g = torch.Generator(device="cpu").manual_seed(h * w)
+    fl = torch.randn((h, w, 64 * G), generator=g).to("cuda", torch.bfloat16)
+    fr = torch.randn((h, w, 64 * G), generator=g).to("cuda", torch.bfloat16)
+    flow = (torch.rand((2, h, w), generator=g) * 8 - 4).cuda()
+    try:
+        native.set_option("corr_fused", 1)
+        a = native.corr_lookup(fl, fr, flow, G, 0)
+        native.set_option("corr_fused", 0)
+        b = native.corr_lookup(fl, fr, flow, G, 0)
+    finally:
+        native.set_option("corr_fused", 1)
+    assert torch.equal(a, b), f"{int((a != b).sum())} of {a.numel()} differ, max {float((a - b).abs().max())}"

@@ -15,7 +15,7 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.2 (gfx950)"; }
 
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 256, 0 };
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 256, 0, 1 };
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
@@ -30,6 +30,7 @@ extern "C" int v3d_set_option(const char* key, int value)
         g_v3d_opt.gf_cols = value;
     }
     else if (!strcmp(key, "corr_gather")) g_v3d_opt.corr_gather = value != 0;
+    else if (!strcmp(key, "corr_fused")) g_v3d_opt.corr_fused = value != 0;
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
     return V3D_OK;
 }

@@ -19,7 +19,8 @@ struct v3d_lib_options {
     int gf_fused;             // 1: single-launch guided filter (a/b rows handed from stage-1 to stage-2 waves through LDS), 0: two sweeps through HBM
     int gf_band;              // rows per workgroup of the fused kernel
     int gf_cols;              // strip width of the fused kernel: 256 (8 waves, two workgroups per CU) or 512 (16 waves, one)
-    int corr_gather;          // 1: fused gather-GEMM correlation (bit-identical, VALU-bound, slower)
+    int corr_gather;          // 1: register-only gather-GEMM correlation (bit-identical, blends every position twice, slower)
+    int corr_fused;           // 1: gather-GEMM through LDS for the 1x9 pattern (warped features never touch HBM), 0: warp kernel + GEMM kernel
 };
 extern v3d_lib_options g_v3d_opt;
 
