@@ -958,10 +958,51 @@ __global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restric
     const int t = threadIdx.x, f = blockIdx.z;
     const int x0 = blockIdx.x * LRM_TX, y0 = blockIdx.y * LRM_TY;
     const size_t fo = (size_t)f * H * W;
-    for (int i = t; i < (LRM_TY + 2) * (LRM_TX + 2); i += 256) {
-        const int ty = i / (LRM_TX + 2), tx = i - ty * (LRM_TX + 2);
-        const int y = min(max(y0 - 1 + ty, 0), H - 1), x = min(max(x0 - 1 + tx, 0), W - 1);     // replicated image border
-        sT[ty][tx] = (short)lr_checked(dispw, d2key, fo + (size_t)y * W, x, W, d12);
+    // The check of one pixel is a chain of dependent loads (disparity -> two right-view keys); a thread owns ~5 pixels of
+    // the staged tile.  All its disparities are fetched first, then all its keys (unconditional loads from clamped
+    // addresses, the range tests applied afterwards): two round trips per thread instead of ten.
+    constexpr int NIT = ((LRM_TY + 2) * (LRM_TX + 2) + 255) / 256;
+    int d1v[NIT]; uint32_t kav[NIT], kbv[NIT];
+    auto tile_xy = [&](int it, int& ty, int& tx, int& x, size_t& rowo) -> bool {
+        const int i = t + 256 * it;
+        const bool on = i < (LRM_TY + 2) * (LRM_TX + 2);
+        const int ic = on ? i : 0;
+        ty = ic / (LRM_TX + 2); tx = ic - ty * (LRM_TX + 2);
+        const int y = min(max(y0 - 1 + ty, 0), H - 1);                        // replicated image border
+        x = min(max(x0 - 1 + tx, 0), W - 1);
+        rowo = fo + (size_t)y * W;
+        return on;
+    };
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int ty, tx, x; size_t rowo;
+        tile_xy(it, ty, tx, x, rowo);
+        d1v[it] = dispw[rowo + x];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int ty, tx, x; size_t rowo;
+        tile_xy(it, ty, tx, x, rowo);
+        const int d1 = d1v[it];
+        const int xa = x - (d1 >> 4), xb = x - ((d1 + 15) >> 4);
+        kav[it] = d2key[rowo + min(max(xa, 0), W - 1)];
+        kbv[it] = d2key[rowo + min(max(xb, 0), W - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int ty, tx, x; size_t rowo;
+        if (!tile_xy(it, ty, tx, x, rowo)) continue;
+        int d1 = d1v[it];
+        if (x < V3D_D) d1 = V3D_INVALID16;
+        else if (d1 != V3D_INVALID16) {                                        // lr_checked(), on the values fetched above
+            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+            const int xa = x - da, xb = x - db;
+            bool bad = true;
+            if (xa >= 0 && xa < W) bad = bad && (kav[it] != 0xFFFFFFFFu) && (abs(63 - (int)(kav[it] & 63u) - da) > d12); else bad = false;
+            if (xb >= 0 && xb < W) bad = bad && (kbv[it] != 0xFFFFFFFFu) && (abs(63 - (int)(kbv[it] & 63u) - db) > d12); else bad = false;
+            if (bad) d1 = V3D_INVALID16;
+        }
+        sT[ty][tx] = (short)d1;
     }
     __syncthreads();
     const int tx = t & (LRM_TX - 1), x = x0 + tx;
