@@ -63,29 +63,45 @@ __global__ __launch_bounds__(256) void k_split_sbs(const uint8_t* __restrict__ s
 #pragma unroll
     for (int k = 0; k < 8; k++) { tp0[k] = taps.t[0][k]; tp1[k] = taps.t[1][k]; }
 
+    // Staging plan of this thread, the same for every row of the band: interior blocks copy ONE aligned dword of the
+    // span (the <= 3 bytes of over-read stay inside the image row); edge blocks copy up to four bytes from clamped
+    // pixels (replicated border).  The plan's loads for row y+1 are issued before row y is computed: a row is ~140
+    // instructions, a load ~1.5 us -- fetched at the top of its own row, every row waited for its bytes.
+    // (Dword copies need a row-invariant alignment: pitch a multiple of 4.  A half row that starts at the row's first
+    //  byte on an unaligned address would be read from up to 3 bytes BEFORE the row -- before the caller's buffer for
+    //  row 0 of frame 0: such blocks take the byte plan.)
+    const uint8_t* col0 = sbs + (size_t)eye * hw * 3;               // this eye's half row starts here in every row
+    const uintptr_t a = reinterpret_cast<uintptr_t>(col0 + (size_t)max(s0, 0) * 3);
+    const bool head_unaligned = (eye | s0) == 0 && (reinterpret_cast<uintptr_t>(col0) & 3) != 0;
+    const bool fast = interior && !head_unaligned && (pitch & 3) == 0;
+    const int soff = fast ? (int)(a & 3) : 0;                       // byte offset of pixel s0 inside sR
+    const int nd = (soff + ns * 3 + 3) >> 2;
+    int boff[4];                                                    // byte plan: source offsets inside the half row
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = min(t + 256 * k, ns * 3 - 1), px = i / 3, c = i - px * 3;
+        boff[k] = min(max(s0 + px, 0), hw - 1) * 3 + c;
+    }
+    uint32_t pre[4] = { 0u, 0u, 0u, 0u };
+    auto load_row = [&](int y) {
+        const uint8_t* row = col0 + (size_t)y * pitch;
+        if (fast) {
+            if (t < nd) pre[0] = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3)) & ~(uintptr_t)3)[t];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) pre[k] = row[boff[k]];
+        }
+    };
+    load_row(ya);
     for (int y = ya; y < yb; y++) {
         uint8_t* sR = sRow[y & 1];                                  // double-buffered: one barrier per row
-        const uint8_t* row = sbs + (size_t)y * pitch + (size_t)eye * hw * 3;     // this eye's half row: hw BGR pixels
-        int soff = 0;                                               // byte offset of pixel s0 inside sR
-        // a half row that starts at the row's first byte on an address that is not dword-aligned would be read from up
-        // to 3 bytes BEFORE the row (before the caller's buffer for row 0 of frame 0): such rows take the byte path.
-        // (uniform per workgroup and row; never true for pitches and bases that are multiples of 4, e.g. torch tensors)
-        const bool head_unaligned = (eye | s0) == 0 && (reinterpret_cast<uintptr_t>(row) & 3) != 0;
-        if (interior && !head_unaligned) {
-            // aligned dword loads of the span; the <= 3 bytes of over-read stay inside this image row
-            // (edge blocks take the clamped byte path)
-            const uintptr_t a = reinterpret_cast<uintptr_t>(row + (size_t)s0 * 3);
-            const uint32_t* a0 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-            soff = (int)(a & 3);
-            const int nd = (soff + ns * 3 + 3) >> 2;
-            for (int i = t; i < nd; i += 256) reinterpret_cast<uint32_t*>(sR)[i] = a0[i];
-        } else {
-            for (int i = t; i < ns * 3; i += 256) {
-                const int px = i / 3, c = i - px * 3;
-                sR[i] = row[min(max(s0 + px, 0), hw - 1) * 3 + c];              // replicate border
-            }
+        if (fast) { if (t < nd) reinterpret_cast<uint32_t*>(sR)[t] = pre[0]; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (t + 256 * k < ns * 3) sR[t + 256 * k] = (uint8_t)pre[k];
         }
         __syncthreads();
+        if (y + 1 < yb) load_row(y + 1);                            // flies while this row is computed
         if (unsqueeze) {
             // source phase: fx = (x + 0.5) * 0.5 - 0.5 -> even x = 2m: sx = m - 1, frac 0.75; odd x = 2m + 1: sx = m, frac 0.25
             const int x = xb + 2 * t;                               // even member of the pair; m = x / 2 = s0 + 4 + t
