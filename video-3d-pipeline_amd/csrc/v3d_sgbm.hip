@@ -1132,12 +1132,11 @@ __global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ 
     const size_t fo = (size_t)blockIdx.z * W * H;
     const int16_t* im = img + fo; int* L = lab + fo;
     const int i = y * W + x;
-    const int v = im[i], u = im[i + W];
+    const int il = i - (x > 0 ? 1 : 0);                        // all four pixels are fetched together (one round trip, not two)
+    const int v = im[i], u = im[i + W], vl = im[il], ul = im[il + W];
     if (!ccl_conn(v, u, newVal, maxDiff)) return;
-    if (x > 0) {      // the pixel to my left joins the same two runs: it (or one further left) does the union
-        const int vl = im[i - 1], ul = im[i + W - 1];
-        if (ccl_conn(vl, ul, newVal, maxDiff) && ccl_conn(vl, v, newVal, maxDiff) && ccl_conn(ul, u, newVal, maxDiff)) return;
-    }
+    // the pixel to my left joins the same two runs: it (or one further left) does the union
+    if (x > 0 && ccl_conn(vl, ul, newVal, maxDiff) && ccl_conn(vl, v, newVal, maxDiff) && ccl_conn(ul, u, newVal, maxDiff)) return;
     ccl_union(L, L[i], L[i + W]);
 }
 
