@@ -81,6 +81,45 @@ def test_round_robin_assignment():
     assert sharding.rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def _cuda_exchange_worker(rank, world, port):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from video_3d_pipeline import sharding
+    sharding.init_process_group("gloo")                       # transport on the host; buffers, streams and events on the GPU
+    dev = torch.device("cuda", 0)
+    H, W = 216, 384
+    ex = sharding.GuideRoundExchange((H, W), dev)
+    nfr = 7 * world + 1
+
+    def rnd(b):
+        return [torch.full((H, W), (1 + b + r) % 251, dtype=torch.uint8, device=dev) if b + r < nfr else None
+                for r in range(world)] if rank == 0 else None
+    ex.post(rnd(0))
+    for b in range(0, nfr, world):
+        if b + world < nfr:
+            ex.post(rnd(b + world))                           # one round ahead, on the exchange's side stream
+        g = ex.take()
+        i = b + rank
+        assert (g is not None) == (i < nfr)
+        if g is not None:
+            assert g.is_cuda and int(g.to(torch.int64).sum().item()) == ((1 + i) % 251) * H * W, i
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_guide_exchange_streams_on_one_gpu():
+    """the exchange's device path -- persistent double-buffered round buffers, side stream, events, pinned validity bytes,
+    slot reuse behind the consumer's copy -- with two ranks sharing the one GPU (gloo carries the bytes): 8 rounds, ragged tail"""
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_cuda_exchange_worker, args=(2, port), nprocs=2, join=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_two_rank_rccl(tmp_path):
