@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, tmp, clip, backend="gloo"):
+def _worker(rank, world, port, tmp, clip, backend="gloo", hip=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd"), os.path.join(ROOT, "tests")):
@@ -26,9 +26,9 @@ def _worker(rank, world, port, tmp, clip, backend="gloo"):
 
     sharding.init_process_group(backend)
     assert sharding.rank_world() == (rank, world)
-    gpu = backend == "nccl"                                    # RCCL: one GPU per rank, the product's HIP backends
+    gpu = backend == "nccl" or hip                             # the product's HIP backends (RCCL: one GPU per rank; gloo + hip: ranks share GPU 0)
     dev = torch.device("cuda", torch.cuda.current_device()) if gpu else torch.device("cpu")
-    if gpu:
+    if backend == "nccl":
         assert torch.cuda.current_device() == rank             # init_process_group selected LOCAL_RANK's GPU
     # 1. guide round broadcast: rank 0 owns the frames, every rank gets its own slot back
     H, W = 6, 10
@@ -56,11 +56,11 @@ def _worker(rank, world, port, tmp, clip, backend="gloo"):
     ex = HybridStereoDepthExtractor(work_dir=os.path.join(tmp, "w"), cache_dir=os.path.join(tmp, "w"), batch_size=2,
                                     stereo_only=True, backend=None if gpu else OracleStereoBackend())
     if gpu:
-        assert ex.backend.device.index == rank                 # a bare "cuda" resolved to this rank's GPU
+        assert ex.backend.device.index == torch.cuda.current_device()      # a bare "cuda" resolved to this rank's GPU
     out = ex.process_video_sbs(clip, max_frames=5, force_reprocess=True)
     dist.barrier()
     if gpu:
-        assert ex.backend._matcher.device.index == rank and ex.backend._matcher.sync_errors() == 0
+        assert ex.backend._matcher.device.index == torch.cuda.current_device() and ex.backend._matcher.sync_errors() == 0
     assert ex.last_decoded_frames == len(range(rank, 5, world))          # ceil(5/2) on rank 0, floor on rank 1
     files = sorted(os.listdir(out))
     assert files == [f"depth_{i:06d}.png" for i in range(5)], files
@@ -136,7 +136,15 @@ def test_two_rank_gloo(tmp_path):
     _two_rank_scenario(tmp_path, "gloo")
 
 
-def _two_rank_scenario(tmp_path, backend):
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_ranks_share_one_gpu(tmp_path):
+    """the sharded product path with the real HIP backends on a one-GPU box: two ranks on GPU 0, gloo as transport --
+    strided decode, one matcher per rank, the guide exchange on device buffers, sharded guided upscale"""
+    _two_rank_scenario(tmp_path, "gloo", hip=True)
+
+
+def _two_rank_scenario(tmp_path, backend, hip=False):
     sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
     from video_3d_pipeline import synthetic as syn
     frames = np.stack([syn.sbs_frame(160, 24, i) for i in range(5)])
@@ -145,7 +153,7 @@ def _two_rank_scenario(tmp_path, backend):
     guides = np.stack([syn.guide_frame(160, 24, i) for i in range(4)])            # 320 x 48 luma, one frame short of the depth maps
     np.save(str(tmp_path / "guide.npy"), np.repeat(guides[..., None], 3, axis=3))
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), clip, backend), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), clip, backend, hip), nprocs=2, join=True)
     # sharded result == single-process result
     from oracle import oracle as O
     from video_3d_pipeline.utils import read_png16
