@@ -24,8 +24,34 @@ def test_corr_matches_oracle(native, oracle, pattern, h, w, G):
     fl_d = torch.from_numpy(fl).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
     fr_d = torch.from_numpy(fr).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
     got = native.corr_lookup(fl_d, fr_d, torch.from_numpy(flow).cuda(), G, pattern).cpu().numpy()
-    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
-    assert np.abs(got - want).max() <= tol, f"max abs err {np.abs(got - want).max():.4e} (tol {tol:.3e})"
+    # per element: SURVEY 8(d)'s rtol 2e-2 plus a floor of 2 % of the typical output (rms) for values near zero
+    rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2)))
+    err, bound = np.abs(got - want), 2e-2 * np.abs(want) + 2e-2 * rms
+    assert (err <= bound).all(), f"worst err/bound {float((err / bound).max()):.3f} (max abs err {float(err.max()):.4e})"
+
+
+@pytest.mark.parametrize("pattern", [0, 1])
+def test_configs3_full_size_against_the_oracle(native, oracle, pattern):
+    """BASELINE configs[3] at its real size (270 x 480 x 256 features, G = 4, both offset patterns) against the fp32 oracle
+    -- not against another HIP kernel.  Per-element bound |got - want| <= 2e-2 |want| + 2e-2 rms(want): SURVEY 8(d)'s
+    rtol 2e-2 plus a floor for outputs near zero (a sum of 64 signed products has no relative accuracy at its zero
+    crossings; the floor is 2 % of the typical output, ~9 sigma of the bf16 rounding of the warped features)."""
+    h, w, G = 270, 480, 4
+    C = 64 * G
+    rng = np.random.default_rng(270 * 480 + pattern)
+    fl = _bf16_round(rng.normal(0, 1, (C, h, w)).astype(np.float32))
+    fr = _bf16_round(rng.normal(0, 1, (C, h, w)).astype(np.float32))
+    flow = rng.uniform(-4, 4, (2, h, w)).astype(np.float32)
+    want = oracle.corr_lookup(fl, fr, flow, G, pattern)
+    fl_d = torch.from_numpy(fl).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
+    fr_d = torch.from_numpy(fr).permute(1, 2, 0).contiguous().to("cuda", torch.bfloat16)
+    got = native.corr_lookup(fl_d, fr_d, torch.from_numpy(flow).cuda(), G, pattern).cpu().numpy()
+    assert got.shape == want.shape == (G * 9, h, w)
+    rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2)))
+    err = np.abs(got - want)
+    bound = 2e-2 * np.abs(want) + 2e-2 * rms
+    worst = float((err / bound).max())
+    assert worst <= 1.0, f"worst err/bound {worst:.3f} (max abs err {float(err.max()):.3e}, rms(want) {rms:.3e})"
 
 
 def test_one_hot_channels_pick_shifted_copies(native):

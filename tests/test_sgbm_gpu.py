@@ -385,6 +385,26 @@ def test_reserved_cus_shrink_the_lockstep_launch(native, oracle):
         assert not mismatch_report(got[i], oracle.sgbm_compute(*pairs[i]), f"frame {i}")
 
 
+def test_oversized_lockstep_launch_waits_instead_of_deadlocking(native, oracle):
+    """k_vdd workgroups draw (frame, strip) tickets in residency order, so a launch with more workgroups than the chip
+    holds (here 96 frames x 8 strips = 768 > 2 x 256 slots, forced with vdd_launch_frames) runs whole frames first and the
+    rest as slots free up: no time-out, the oracle's bits.  (Rounds 1-2 needed every workgroup of a launch resident.)"""
+    import torch
+    W, H, n, nd = 64 + 1000, 48, 96, 3
+    pairs = [textured_pair(W, H, seed=300 + i) for i in range(nd)]
+    want = [oracle.sgbm_compute(*p) for p in pairs]
+    m = native.StereoSGBM(max_width=W, max_height=H, max_batch=n, options={"vdd_dpl": 8, "vdd_launch_frames": n})
+    assert m.get_option("vdd_frames_per_launch_dpl8") < n, "the launch must exceed the co-residency bound"
+    Ls = _dev(native, np.stack([pairs[i % nd][0] for i in range(n)]))
+    Rs = _dev(native, np.stack([pairs[i % nd][1] for i in range(n)]))
+    for rep in range(2):
+        got = m.compute(Ls, Rs)
+        assert m.sync_errors() == 0
+        for i in range(n):
+            assert torch.equal(got[i].cpu(), torch.from_numpy(want[i % nd])), f"frame {i} rep {rep}"
+    m.close()
+
+
 @pytest.mark.parametrize("W,H", [(300, 40), (64, 9), (1, 5), (257, 1), (640, 33)])
 def test_speckle_run_lists_extremes(native, oracle, W, H):
     """the run-list CCL at its corners: every pixel its own run (a full run list without end marker, > 64 runs per row

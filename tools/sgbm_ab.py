@@ -30,6 +30,6 @@ for rnd in range(int(os.environ.get("ROUNDS", "2"))):
         tot = sum(st.values()) / calls
         ms.setdefault(v, []).append(tot)
         if rnd == 0:
-            print(f"{v:22s} total {tot:7.3f} ms/batch  " + " ".join(f"{k.replace('chain_', '')}={x / calls:.3f}" for k, x in st.items() if x / calls > 0.01) + ("  OK" if chk == ref else "  MISMATCH"))
+            print(f"{v:22s} total {tot:7.3f} ms/batch  " + " ".join(f"{k.replace('chain_', '')}={x / calls:.3f}" for k, x in st.items() if x / calls > 0.01) + ("  OK" if chk == ref else "  MISMATCH") + f" chk={chk}")
         m.close()
 for v in variants: print(f"{v:22s} min {min(ms[v]):.3f} ms/batch -> {min(ms[v]) / B:.3f} ms/frame")

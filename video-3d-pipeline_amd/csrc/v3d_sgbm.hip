@@ -10,11 +10,29 @@
 // HBM layout (per frame, W1 = W - 64):
 //   rec        : uint4 [H][W]        pre-filter records, left then right image: {grad, grad_lo, grad_hi, 0 | raw, raw_lo, raw_hi, 0}
 //   C, S       : int16 [H][W1][64]   d fastest: one pixel = one 128-B line
-//   dispw      : int16 [H][W]        WTA output; d2key u32 [H][W] right-view (cost<<6 | 63-d) min-keys
+//   wta        : u32 [H][W]          WTA record per pixel (min S, sub-pixel disparity, winning d); the right-view map is
+//                                    formed from it inside k_lrcheck_median (LDS min-scatter), never in HBM
 #include "v3d_common.h"
 #include <vector>
 #include <string.h>
 #include <type_traits>
+
+// ---- experiment switches (tools/build_variant.sh; every default = the product path) ----
+#ifndef V3D_RIL
+#define V3D_RIL 1               // rows of a volume interleaved in groups of V3D_RIL at pixel granularity (1 = plain [H][W1][64])
+#endif
+#ifndef V3D_X_SPLIT
+#define V3D_X_SPLIT 0           // 1: k_hfused's phase 1 (left->right scan, checkpoints) as its own launch k_hscan
+#endif
+#ifndef V3D_X_C12
+#define V3D_X_C12 0             // timing proxies of a 12-bit C: 1 k_hfused loads, 2 k_vdd<8> loads, 4 k_cost stores (results garbage)
+#endif
+#ifndef V3D_X_COSTCHAIN
+#define V3D_X_COSTCHAIN 0       // timing proxy: one SGM chain step per row inside k_cost (VALU cost of hosting the left path there)
+#endif
+#define VOL_PX (V3D_RIL * V3D_D)                                   // elements between pixel x and x + 1 of a row
+__host__ __device__ static inline size_t vol_row(int y, int W1) { return ((size_t)(y / V3D_RIL) * W1 * V3D_RIL + (size_t)(y % V3D_RIL)) * V3D_D; }
+__host__ __device__ static inline size_t vol_frame(int H, int W1) { return (size_t)((H + V3D_RIL - 1) / V3D_RIL) * V3D_RIL * W1 * V3D_D; }
 
 // ------------------------------------------------------------------------------------------------
 // a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
@@ -112,9 +130,6 @@ template <int LPC> struct CostGeo {
 #ifndef V3D_COST_LPC
 #define V3D_COST_LPC 8
 #endif
-#ifndef V3D_COST_DBG
-#define V3D_COST_DBG 0          // experiment builds only: 1 no right-plane reads, 2 no hsum reads, 4 no staging writes, 8 no left reads
-#endif
 
 __device__ __forceinline__ uint32_t bt_pair(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
 {
@@ -130,6 +145,8 @@ template <> struct VecT<8> { typedef uint4 type; };
 template <> struct VecT<4> { typedef uint2 type; };
 template <int NP> __device__ __forceinline__ void vec_unpack(const uint4& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
 template <int NP> __device__ __forceinline__ void vec_unpack(const uint2& v, uint32_t (&r)[NP]) { r[0] = v.x; r[1] = v.y; }
+__device__ __forceinline__ void vec_repack(uint4& v, const uint32_t (&r)[4]) { v = make_uint4(r[0], r[1], r[2], r[3]); }
+__device__ __forceinline__ void vec_repack(uint2& v, const uint32_t (&r)[4]) { v = make_uint2(r[0], r[1]); }
 __device__ __forceinline__ uint4 vec_pack4(const uint32_t (&r)[4]) { return make_uint4(r[0], r[1], r[2], r[3]); }
 __device__ __forceinline__ uint2 vec_pack2(const uint32_t (&r)[2]) { return make_uint2(r[0], r[1]); }
 template <int NP> struct Packer;
@@ -139,7 +156,10 @@ template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const 
 // (Tried and dropped: letting the vertical SGM path ride along in this kernel -- the lane layout is k_chain's,
 // but the unbanded kernel it needs has too few waves to gain anything.)
 template <int LPC>
-__global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
+#ifndef V3D_COST_WAVES
+#define V3D_COST_WAVES 6
+#endif
+__global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __restrict__ rec,
                                               int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C, int xcd_order)
 {
     typedef CostGeo<LPC> G;
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
     const int ys = byi * band_h, ye = min(ys + band_h, H);
     const int f = bzi;
     const uint32_t* rf = reinterpret_cast<const uint32_t*>(rec + (size_t)f * H * W);   // 4 dwords per pixel
-    int16_t* Cf = C + (size_t)f * H * W1 * V3D_D;
+    int16_t* Cf = C + (size_t)f * vol_frame(H, W1);
 
     const int xrc = min(max(xr0 - 2 + col, 0), W1 - 1);        // clamped cost-region column of this lane
     // staged record i <-> image column xr0 - 1 + i; reversed element k = NREC-1 - i.  d = EP*dq + j reads record
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
     };
     // every VMEM instruction of the row loop is issued unconditionally (v3d_common.h: raw buffer access): threads
     // that stage nothing, halo columns and the warm-up rows are switched off through an out-of-range offset
-    const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)H * W1 * (V3D_D * 2u));
+    const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)(vol_frame(H, W1) * 2u));
     const uint32_t la = ld_any ? ld_a * 4u : V3D_BUF_OOB, lb = ld_any ? ld_b * 4u : V3D_BUF_OOB;   // + row offset < 2^31: bit 31 survives
     auto fetch = [&](int k) -> uint2 {
         const uint32_t ro = (uint32_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 16u;
@@ -230,7 +250,12 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
 #pragma unroll
         for (int i = 0; i < 5; i++) ring[i][j] = 0u; }
     // C store offsets: per-thread part (out-of-range marker for halo columns) + uniform row part
-    const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * V3D_D + EP * dq) * 2u : V3D_BUF_OOB;
+    const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * VOL_PX + EP * dq) * 2u : V3D_BUF_OOB;
+#if V3D_X_COSTCHAIN
+    uint32_t xp[NP], xdelta = pk_bcast(P2);
+#pragma unroll
+    for (int j = 0; j < NP; j++) xp[j] = 0u;
+#endif
 
     for (int k10 = 0; k10 < nrows; k10 += 10) {
 #pragma unroll
@@ -248,10 +273,10 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
             uint32_t U[3], V[3][NP];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                U[i] = (V3D_COST_DBG & 8) ? (uint32_t)(tid + i + k) : sUL[buf][col][3 * pl + i];
+                U[i] = sUL[buf][col][3 * pl + i];
                 const uint32_t* pr = &sRV[buf * RBUF + rv_off + (3 * pl + i) * RROW];
 #pragma unroll
-                for (int j = 0; j < NP; j++) V[i][j] = (V3D_COST_DBG & 1) ? (uint32_t)(tid * 3 + i + j + k) : pr[j];
+                for (int j = 0; j < NP; j++) V[i][j] = pr[j];
             }
 #pragma unroll
             for (int j = 0; j < NP; j++) {
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
         }
         sPix[buf][col][dq] = Packer<NP>::go(pix);
 
-        if (k + 1 < nrows && ld_any && !(V3D_COST_DBG & 4)) stage(buf ^ 1, nr[buf ^ 1]);     // row k+1 has parity buf^1 (k10 is even)
+        if (k + 1 < nrows && ld_any) stage(buf ^ 1, nr[buf ^ 1]);     // row k+1 has parity buf^1 (k10 is even)
         nr[buf ^ 1] = fetch(k + 3);
         __syncthreads();
 
@@ -273,14 +298,35 @@ __global__ __launch_bounds__(512, 6) void k_cost(const uint4* __restrict__ rec,
             vec_unpack<NP>(sPix[buf][hc - 2][dq], h);               // (halo lanes re-sum a neighbour's window; never stored)
 #pragma unroll
             for (int t = -1; t <= 2; t++) {
-                if (V3D_COST_DBG & 2) { for (int j = 0; j < NP; j++) w[j] = h[j] + t; } else
                 vec_unpack<NP>(sPix[buf][hc + t][dq], w);
 #pragma unroll
                 for (int j = 0; j < NP; j++) h[j] += w[j];      // halves <= 5 * 189: no carry
             }
 #pragma unroll
             for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
-            const uint32_t st_row = k >= 4 ? (uint32_t)((ys + k - 4) * W1) * (V3D_D * 2u) : V3D_BUF_OOB;     // uniform
+            const uint32_t st_row = k >= 4 ? (uint32_t)(vol_row(ys + k - 4, W1) * 2u) : V3D_BUF_OOB;     // uniform
+#if V3D_X_COSTCHAIN
+            {   // timing proxy: the left-path recurrence hosted here (one chain step per row on the fresh C vector, a checkpoint
+                // every 16 rows into the tail of the row's own C line -- results garbage)
+                uint32_t Lx[NP];
+                xdelta = chain_step<NP, LPC>(xp, xdelta, vs, Lx, pk_bcast(600), pk_bcast(P2), dq == 0, dq == LPC - 1);
+#pragma unroll
+                for (int j = 0; j < NP; j++) xp[j] = Lx[j];
+                if ((k & 15) == 15) buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(xp));
+            }
+#endif
+#if V3D_X_C12 & 4
+            if (NP == 4) {   // timing proxy of a 12-bit C: pack 8 x 12 bits into three dwords, one 12-byte store per lane
+                uint32_t t[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[j] = (vs[j] & 0xFFFu) | ((vs[j] >> 4) & 0xFFF000u);
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                const u32x3 pk = { t[0] | (t[1] << 24), (t[1] >> 8) | (t[2] << 16), (t[2] >> 16) | (t[3] << 8) };
+                const uint32_t c12 = out_col ? (uint32_t)((xr0 - 2 + col) * 96 + 12 * dq) : V3D_BUF_OOB;
+                const uint32_t r12 = k >= 4 ? (uint32_t)((ys + k - 4) * W1) * 96u : V3D_BUF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b96(pk, rs_c, __builtin_elementwise_add_sat(c12, r12), 0, V3D_NT ? 2 : 0);
+            } else
+#endif
             buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(vs));   // saturating: marker + marker stays out of range
         }
       }
@@ -302,8 +348,7 @@ struct ChainArgs {
     int W1, H, W, nframes;
     int P1, P2;
     int uniq;                 // uniquenessRatio
-    int16_t* dispw;           // MODE 2: [nframes][H][W]
-    uint32_t* d2key;          // MODE 2: [nframes][H][W]
+    uint32_t* wta;            // MODE 2: [nframes][H][W] WTA records (wta_word); columns < 64 are never written
     int xcd;                  // k_hfused: XCD-contiguous row-group order (V3D_HF_XCD=1).  Measured 4 % slower: off
 };
 
@@ -363,6 +408,11 @@ __device__ __forceinline__ uint32_t chain_delta(const uint32_t (&p)[NP], uint32_
 
 #define WTA_ROWB 144   // bytes per pixel row in LDS (128 + 16 pad, keeps 16-B alignment)
 
+// WTA record of one cost-region pixel: [31:17] min S (< 32767), [16:6] d16 + 16 (0 = invalid pixel), [5:0] winning d.
+// One plain store per pixel; the right-view map is formed from these records in k_lrcheck_median.
+__device__ __forceinline__ uint32_t wta_word(int minS, int d16, int best) { return ((uint32_t)minS << 17) | ((uint32_t)(d16 + 16) << 6) | (uint32_t)best; }
+__device__ __forceinline__ int wta_d16(uint32_t w) { return (int)((w >> 6) & 0x7FFu) - 16; }
+
 // winner-take-all for one pixel whose 64 aggregated costs sit in LDS (stereosgbm.cpp per-row tail)
 __device__ __forceinline__ void wta_pixel(const unsigned char* srow, bool valid, int x, int y, int frame,
                                           const ChainArgs& a)
@@ -406,18 +456,16 @@ __device__ __forceinline__ void wta_pixel(const unsigned char* srow, bool valid,
     if (best < V3D_D - 1 && sp < T1) cw++;
     const bool ok = valid && (minS < V3D_MAX_COST) && (cnt <= cw);
     if (!valid) return;
-    int d16 = V3D_INVALID16;
+    uint32_t word = 0u;                                        // invalid
     if (ok) {
-        const size_t rowo = ((size_t)frame * a.H + y) * a.W;
-        const int ximg = x + V3D_D;
-        atomicMin(&a.d2key[rowo + ximg - best], ((uint32_t)minS << 6) | (uint32_t)(63 - best));
+        int d16 = best * 16;
         if (best > 0 && best < V3D_D - 1) {
             const int den = max(sm + sp - 2 * minS, 1);
-            d16 = best * 16 + ((sm - sp) * 16 + den) / (den * 2);
-        } else
-            d16 = best * 16;
+            d16 += ((sm - sp) * 16 + den) / (den * 2);
+        }
+        word = wta_word(minS, d16, best);
     }
-    a.dispw[((size_t)frame * a.H + y) * a.W + x + V3D_D] = (int16_t)d16;
+    a.wta[((size_t)frame * a.H + y) * a.W + x + V3D_D] = word;
 }
 
 template <bool HORIZ, int XS, bool YREV, int MODE, int DPL>
@@ -451,8 +499,8 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
     else if (XS > 0) { tlo = max(0, H - 1 - c1); thi = min(H, W1 + H - 1 - c0); }
     else { tlo = max(0, c0 - (W1 - 1)); thi = min(H, c1 + 1); }
 
-    const int16_t* Cf = a.C + (size_t)frame * H * W1 * V3D_D + dl * DPL;
-    int16_t* Sf = a.S + (size_t)frame * H * W1 * V3D_D + dl * DPL;
+    const int16_t* Cf = a.C + (size_t)frame * vol_frame(H, W1) + dl * DPL;
+    int16_t* Sf = a.S + (size_t)frame * vol_frame(H, W1) + dl * DPL;
     const int x0 = HORIZ ? 0 : (XS == 0 ? cc : (XS > 0 ? cc - (H - 1) : cc));
 
     auto pos = [&](int t, int& x, int& y) {
@@ -462,7 +510,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
     auto elem_off = [&](int t) -> int {
         int x, y; pos(t, x, y);
         x = min(max(x, 0), W1 - 1);
-        return (y * W1 + x) * V3D_D;
+        return (int)(vol_row(y, W1) + (size_t)x * VOL_PX);
     };
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
@@ -545,7 +593,68 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
 // run L_right backwards over it, form S + L_left + L_right on chip and do the WTA tail.
 // Cost: L_left is computed twice (+1 path of VALU), C is read twice, S once, never written.
 // ------------------------------------------------------------------------------------------------
+// 12-bit C timing proxy (V3D_X_C12 & 1): a lane's 4 disparities are 6 bytes at byte offset 6 * dl of a 96-byte pixel
+typedef uint32_t v3d_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t v3d_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ uint32_t unpack12_pair(uint32_t t) { return (t & 0xFFFu) | ((t << 4) & 0x0FFF0000u); }
+template <int DPL> struct HfC {
+    typedef typename VecT<DPL>::type Vec;
+    // pointer to the lane's disparities of pixel (row, x = 0) and the load of pixel x
+    static __device__ __forceinline__ const char* base(const int16_t* C, int frame, int H, int W1, int row, int dl)
+    {
+#if V3D_X_C12 & 1
+        if (DPL == 4) return reinterpret_cast<const char*>(C) + ((size_t)frame * H + row) * W1 * 96 + ((6 * dl) & ~3);
+#endif
+        return reinterpret_cast<const char*>(C + (size_t)frame * vol_frame(H, W1) + vol_row(row, W1) + dl * DPL);
+    }
+    static __device__ __forceinline__ Vec load(const char* b, int x, int dl)
+    {
+#if V3D_X_C12 & 1
+        if (DPL == 4) {
+            const v3d_u32x2_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x2_a4*>(b + (size_t)x * 96));
+            const uint32_t sh = (dl & 1) * 16;
+            const uint32_t lo = alignbit(v.y, v.x, sh), hi = v.y >> sh;
+            Vec r; r.x = unpack12_pair(lo); r.y = unpack12_pair(alignbit(hi, lo, 24));
+            return r;
+        }
+#endif
+        return ld_stream(reinterpret_cast<const Vec*>(b + (size_t)x * (VOL_PX * 2)));
+    }
+};
+
+// ---------------- phase 1: left -> right over blocks 0 .. nblk-2, checkpoint at every block start ----------------
 template <int DPL>
+__device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nblk, int dl, uint32_t P1pk, uint32_t P2pk)
+{
+    constexpr int NP = DPL / 2, LPP = 64 / DPL, K = 64 / DPL;
+    typedef typename VecT<DPL>::type Vec;
+    const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
+    uint32_t p[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) p[i] = 0;
+    uint32_t delta = P2pk;
+    const int xend = (nblk - 1) * K;                       // the last block is recomputed in phase 2 anyway
+    for (int xb = 0; xb < xend; xb += K) {
+        // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
+        Vec cb[K];
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) cb[jj] = HfC<DPL>::load(Crow, xb + jj, dl);
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            uint32_t cv[NP], L[NP];
+            vec_unpack<NP>(cb[jj], cv);
+            delta = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
+#pragma unroll
+            for (int i = 0; i < NP; i++) p[i] = L[i];
+        }
+        uint32_t* c = ck + (size_t)(xb / K + 1) * NP * 64;
+#pragma unroll
+        for (int i = 0; i < NP; i++) c[i * 64] = p[i];
+    }
+}
+
+// PH: 3 = both phases in one launch; 2 = phase 2 only (k_hscan has dropped the checkpoints before)
+template <int DPL, int PH>
 __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restrict__ ckpt)
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW;
@@ -562,39 +671,15 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     const int sub = lane / LPP, dl = lane % LPP;
     const int c0 = grp * PPW, c1 = min(c0 + PPW, H) - 1;
     const int cc = min(c0 + sub, c1);
-    const int16_t* Crow = a.C + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
-    const int16_t* Srow = a.S + ((size_t)frame * H + cc) * W1 * V3D_D + dl * DPL;
+    const char* Crow = HfC<DPL>::base(a.C, frame, H, W1, cc, dl);
+    const int16_t* Srow = a.S + (size_t)frame * vol_frame(H, W1) + vol_row(cc, W1) + dl * DPL;
     const int nblk = (W1 + K - 1) / K;
     uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;         // [blk][reg][lane]; delta is recomputed
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
     const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
 
-    // ---------------- phase 1: left -> right over blocks 0 .. nblk-2, checkpoint at every block start ----------------
-    {
-        uint32_t p[NP];
-#pragma unroll
-        for (int i = 0; i < NP; i++) p[i] = 0;
-        uint32_t delta = P2pk;
-        const int xend = (nblk - 1) * K;                       // the last block is recomputed in phase 2 anyway
-        for (int xb = 0; xb < xend; xb += K) {
-            // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
-            Vec cb[K];
-#pragma unroll
-            for (int jj = 0; jj < K; jj++) cb[jj] = ld_stream(reinterpret_cast<const Vec*>(Crow + (size_t)(xb + jj) * V3D_D));
-#pragma unroll
-            for (int jj = 0; jj < K; jj++) {
-                uint32_t cv[NP], L[NP];
-                vec_unpack<NP>(cb[jj], cv);
-                delta = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
-#pragma unroll
-                for (int i = 0; i < NP; i++) p[i] = L[i];
-            }
-            uint32_t* c = ck + (size_t)(xb / K + 1) * NP * 64;
-#pragma unroll
-            for (int i = 0; i < NP; i++) c[i * 64] = p[i];
-        }
-    }
+    if (PH & 1) hf_phase1<DPL>(Crow, ck, nblk, dl, P1pk, P2pk);
 
     // ---------------- phase 2: right -> left, block by block ----------------
     unsigned char* myS = sS + wib * 64 * WTA_ROWB;
@@ -617,9 +702,9 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
         Vec cvv[K], svv[K];
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const size_t o = (size_t)min(x0 + j, W1 - 1) * V3D_D;
-            cvv[j] = ld_stream(reinterpret_cast<const Vec*>(Crow + o));
-            svv[j] = ld_stream(reinterpret_cast<const Vec*>(Srow + o));
+            const int xj = min(x0 + j, W1 - 1);
+            cvv[j] = HfC<DPL>::load(Crow, xj, dl);
+            svv[j] = ld_stream(reinterpret_cast<const Vec*>(Srow + (size_t)xj * VOL_PX));
         }
         uint32_t p[NP], delta = P2pk;
 #pragma unroll
@@ -660,6 +745,26 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     }
 }
 
+// phase 1 of k_hfused as its own launch: it needs a dozen registers where phase 2 needs 119, so on its own it runs at twice
+// the occupancy and keeps twice the bytes in flight per CU
+template <int DPL>
+__global__ __launch_bounds__(256, 8) void k_hscan(ChainArgs a, uint32_t* __restrict__ ckpt)
+{
+    constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int W1 = a.W1, H = a.H;
+    const int groups = (H + PPW - 1) / PPW;
+    const int gw = (int)blockIdx.x * 4 + wib;
+    const int frame = gw / groups, grp = gw - frame * groups;
+    if (frame >= a.nframes) return;
+    const int sub = lane / LPP, dl = lane % LPP;
+    const int c0 = grp * PPW, c1 = min(c0 + PPW, H) - 1;
+    const int cc = min(c0 + sub, c1);
+    const int nblk = (W1 + K - 1) / K;
+    uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;
+    hf_phase1<DPL>(HfC<DPL>::base(a.C, frame, H, W1, cc, dl), ck, nblk, dl, pk_bcast(a.P1), pk_bcast(a.P2));
+}
+
 // ------------------------------------------------------------------------------------------------
 // a-5, the three top-down paths r1 = (x-1, y-1), r2 = (x, y-1), r3 = (x+1, y-1) in ONE pass over C
 // (SURVEY 8a-5's K_v): reads C once, writes S = L1 + L2 + L3 once -- 2 volumes instead of the
@@ -672,9 +777,14 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 //   * across strips the edge columns' state travels through global memory as 8-byte {data, tag} granules
 //     (relaxed agent-scope atomic stores / loads: sc1, served by L2, no fences -- MI355X_MICROARCH
 //     "handoff-1to1"), tag = (call sequence << 12) | (row + 1), 4-row ring per strip edge (stays in L2).
-// The coupling is bidirectional (strip k waits for k-1 AND k+1), so ALL strips of a launch must be
-// co-resident: the host sizes the launch from the occupancy query (with margin) and splits larger
-// batches; every spin is bounded and trips an error flag instead of hanging.
+// The coupling is bidirectional (strip k waits for k-1 AND k+1), so the strips of ONE FRAME must be co-resident;
+// frames are independent.  A workgroup therefore takes its (frame, strip) from a TICKET drawn when it starts running
+// (one atomicAdd), not from blockIdx: tickets are handed out in residency order, so the resident workgroups always
+// hold the lowest tickets = whole frames plus at most one partial frame, and a partial frame merely waits (bounded
+// spin) until finished frames free slots for its remaining strips.  A launch larger than the chip -- or a chip that
+// has lost slots to another tenant -- slows down instead of dead-locking; the host still sizes launches to the
+// occupancy query (no margin needed) because a waiting partial frame costs a whole extra pass.  Every spin is
+// bounded and trips an error flag instead of hanging.
 // ------------------------------------------------------------------------------------------------
 #define VDD_RING 4
 #define VDD_GRAN 34                      // granules per edge per row: 32 data dwords + delta (+1 pad)
@@ -691,6 +801,8 @@ struct VddArgs {
     uint32_t seq;
     int spin_limit;                     // poll rounds a lane may spend waiting over the whole pass
     unsigned long long* gran;           // [frame][strip][2 dirs][VDD_RING][VDD_GRAN]
+    uint32_t* ticket;                   // running counter of started workgroups (all launches of the handle)
+    uint32_t ticket_base;               // its value before this launch
     int* err;
     int xcd;                            // 1: XCD-contiguous strip order.  Measured slower (3.48 -> 4.58 ms per 30 frames): off
 };
@@ -737,20 +849,23 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     __shared__ Vec sL3[2][PXS + 2][LPP];
     __shared__ uint2 sDl[2][PXS + 2];
 
+    __shared__ uint32_t sTicket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave index as an SGPR: edge-wave branches stay scalar
     const int px = wv * PPW + lane / LPP, dl = lane % LPP;      // pixel inside the strip, disparity group
-    const int vb = a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    if (tid == 0) sTicket = atomicAdd(a.ticket, 1u) - a.ticket_base;      // residency order (see above); wraps with the counter
+    __syncthreads();
+    const uint32_t tk = __builtin_amdgcn_readfirstlane(sTicket);
+    const int vb = a.xcd ? (int)xcd_linear(tk, gridDim.x) : (int)tk;
     const int frame = vb / a.nstrips, strip = vb - frame * a.nstrips;
     const int W1 = a.W1, H = a.H;
     const int x = strip * PXS + px;
     const bool colok = x < W1;
     const bool ragged = __builtin_amdgcn_readfirstlane((strip + 1) * PXS > W1);   // this strip sticks out of the image
     const int xc = min(x, W1 - 1);
-    const size_t fbase = (size_t)frame * H * W1 * V3D_D;
-    const int16_t* Cp = a.C + fbase + (size_t)xc * V3D_D + dl * DPL;
-    int16_t* Sp = a.S + fbase + (size_t)xc * V3D_D + dl * DPL;
-    const size_t rstride = (size_t)W1 * V3D_D;
+    const size_t fbase = (size_t)frame * vol_frame(H, W1);
+    const int16_t* Cp = a.C + fbase + (size_t)xc * VOL_PX + dl * DPL;
+    int16_t* Sp = a.S + fbase + (size_t)xc * VOL_PX + dl * DPL;
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
     const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
@@ -777,10 +892,23 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     for (int i = 0; i < NP; i++) p2[i] = 0u;
 
     Vec cq[PF];
-    auto rowof = [&](int y) -> size_t { const int yc = min(y, H - 1); return (size_t)(YREV ? H - 1 - yc : yc) * rstride; };
+    auto rowof = [&](int y) -> size_t { const int yc = min(y, H - 1); return vol_row(YREV ? H - 1 - yc : yc, W1); };
+#if V3D_X_C12 & 2
+    // timing proxy of a 12-bit C: a lane's 8 disparities are 12 bytes of a 96-byte pixel (results garbage)
+    const char* Cp12 = reinterpret_cast<const char*>(a.C) + ((size_t)frame * H * W1 + xc) * 96 + dl * 12;
+    auto ld_c = [&](int y) -> Vec {
+        if (DPL != 8) return ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y)));
+        const int yc = min(y, H - 1);
+        const v3d_u32x3_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x3_a4*>(Cp12 + (size_t)(YREV ? H - 1 - yc : yc) * W1 * 96));
+        uint32_t r[4] = { unpack12_pair(v.x), unpack12_pair(alignbit(v.y, v.x, 24)), unpack12_pair(alignbit(v.z, v.y, 16)), unpack12_pair(v.z >> 8) };
+        Vec o; vec_repack(o, r); return o;
+    };
+#else
+    auto ld_c = [&](int y) -> Vec { return ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y))); };
+#endif
     Vec sq[PF];
 #pragma unroll
-    for (int j = 0; j < PF; j++) { cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(j))); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
+    for (int j = 0; j < PF; j++) { cq[j] = ld_c(j); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
     __syncthreads();
 
     // The row loop exists twice: waves that own a strip-edge pixel (wave 0 / wave 15 of an inner strip) carry the
@@ -801,7 +929,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 uint32_t sold[NP];
                 vec_unpack<NP>(cq[j], cv);
                 if (YREV) vec_unpack<NP>(sq[j], sold);
-                cq[j] = ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y + PF)));
+                cq[j] = ld_c(y + PF);
                 if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(y + PF)));
                 vec_unpack<NP>(sL1[prev][px][dl], p1);             // column x-1 (slot px holds pixel px-1)
                 vec_unpack<NP>(sL3[prev][px + 2][dl], p3);         // column x+1
@@ -885,30 +1013,6 @@ __global__ __launch_bounds__(256) void k_vdd_guard(const int* __restrict__ err, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// a-7: L-R consistency check; also writes the always-invalid columns x < 64.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
-                                                 int W, int H, int d12, int16_t* __restrict__ out)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
-    const size_t rowo = ((size_t)f * H + y) * W;
-    int d1 = V3D_INVALID16;
-    if (x >= V3D_D) {
-        d1 = dispw[rowo + x];
-        if (d1 != V3D_INVALID16) {
-            const int da = d1 >> 4, db = (d1 + 15) >> 4;
-            const int xa = x - da, xb = x - db;
-            bool bad = true;
-            if (xa >= 0 && xa < W) { const uint32_t k = d2key[rowo + xa]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - da) > d12); } else bad = false;
-            if (xb >= 0 && xb < W) { const uint32_t k = d2key[rowo + xb]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - db) > d12); } else bad = false;
-            if (bad) d1 = V3D_INVALID16;
-        }
-    }
-    out[rowo + x] = (int16_t)d1;
-}
-
-// ------------------------------------------------------------------------------------------------
 // a-8: medianBlur(3) on int16 with replicated borders (the invalid value takes part like any other).
 // ------------------------------------------------------------------------------------------------
 #define V3D_SORT2(a, b) { const int _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }
@@ -931,86 +1035,84 @@ __global__ __launch_bounds__(256) void k_median3x3(const int16_t* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
-// a-7 + a-8 fused: L-R check and 3x3 median in one launch.  A block L-R-checks a 64 x 4 tile plus a
-// one-pixel ring into LDS (each pixel checked once, 1.6x halo work instead of 9x), then takes the medians
-// from LDS: saves a launch and the write + read of the intermediate image.
+// a-6 (right-view map) + a-7 + a-8: disp2, L-R check and 3x3 median in one launch.
+//
+// The WTA tail leaves ONE 32-bit record per cost-region pixel (wta_word): min S, the sub-pixel disparity and the
+// winning d.  OpenCV's right-view map -- disp2[x2] = the d of the cheapest pixel x with x - d == x2, later-processed
+// (smaller) x losing ties -- is the minimum of the keys (min S << 6 | 63 - d) over the 64 source pixels x2 .. x2 + 63.
+// Rounds 1-2 formed it with a global atomicMin per pixel inside the WTA tail (60 M L2 atomics per 30 frames: 0.3 ms of
+// k_hfused's 4.9, measured by a build without them); now a block of this kernel stages the records of 256 source
+// columns x 18 rows ONCE (coalesced dword loads instead of two gathers per pixel), min-scatters their keys into an
+// LDS row of right-view targets (ds_min_u32), and checks / medians out of LDS.  Same minimum over the same key set:
+// bit-identical, schedule-independent.
+// Tile: 128 x 16 outputs + a one-pixel ring; sources x0 - 64 .. x0 + 191 (one per thread), targets x0 - 64 .. x0 + 128.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lr_checked(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
-                                          size_t rowo, int x, int W, int d12)
+#define LRM_TX 128
+#define LRM_TY 16
+#define LRM_NS (LRM_TX + 2 * V3D_D)        // source columns per row  (256 = one per thread)
+#define LRM_NT (LRM_TX + V3D_D + 1)        // right-view targets per row
+template <bool MED>
+__global__ __launch_bounds__(256) void k_lrcheck_median(const uint32_t* __restrict__ wta, int W, int H, int d12, int16_t* __restrict__ out)
 {
-    if (x < V3D_D) return V3D_INVALID16;
-    int d1 = dispw[rowo + x];
-    if (d1 == V3D_INVALID16) return d1;
-    const int da = d1 >> 4, db = (d1 + 15) >> 4;
-    const int xa = x - da, xb = x - db;
-    bool bad = true;
-    if (xa >= 0 && xa < W) { const uint32_t k = d2key[rowo + xa]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - da) > d12); } else bad = false;
-    if (xb >= 0 && xb < W) { const uint32_t k = d2key[rowo + xb]; bad = bad && (k != 0xFFFFFFFFu) && (abs(63 - (int)(k & 63u) - db) > d12); } else bad = false;
-    return bad ? V3D_INVALID16 : d1;
-}
-
-#define LRM_TX 64
-#define LRM_TY 16     // 4 outputs per thread: a quarter of the workgroups of a 64 x 4 tile and 1.16x (not 1.55x) halo work
-__global__ __launch_bounds__(256) void k_lrcheck_median(const int16_t* __restrict__ dispw, const uint32_t* __restrict__ d2key,
-                                                        int W, int H, int d12, int16_t* __restrict__ out)
-{
-    __shared__ short sT[LRM_TY + 2][LRM_TX + 2];
+    static_assert(LRM_NS == 256, "one source column per thread");
+    constexpr int NR = LRM_TY + 2;
+    __shared__ uint32_t sW[NR][LRM_NS];
+    __shared__ uint32_t sD2[NR][LRM_NT + 3];
+    __shared__ short sT[NR][LRM_TX + 2];
     const int t = threadIdx.x, f = blockIdx.z;
     const int x0 = blockIdx.x * LRM_TX, y0 = blockIdx.y * LRM_TY;
     const size_t fo = (size_t)f * H * W;
-    // The check of one pixel is a chain of dependent loads (disparity -> two right-view keys); a thread owns ~5 pixels of
-    // the staged tile.  All its disparities are fetched first, then all its keys (unconditional loads from clamped
-    // addresses, the range tests applied afterwards): two round trips per thread instead of ten.
-    constexpr int NIT = ((LRM_TY + 2) * (LRM_TX + 2) + 255) / 256;
-    int d1v[NIT]; uint32_t kav[NIT], kbv[NIT];
-    auto tile_xy = [&](int it, int& ty, int& tx, int& x, size_t& rowo) -> bool {
-        const int i = t + 256 * it;
-        const bool on = i < (LRM_TY + 2) * (LRM_TX + 2);
-        const int ic = on ? i : 0;
-        ty = ic / (LRM_TX + 2); tx = ic - ty * (LRM_TX + 2);
-        const int y = min(max(y0 - 1 + ty, 0), H - 1);                        // replicated image border
-        x = min(max(x0 - 1 + tx, 0), W - 1);
-        rowo = fo + (size_t)y * W;
-        return on;
-    };
+    const int xbase = x0 - V3D_D;                                            // image column of source / target index 0
+    // ---- 1. this thread's source column, all rows in flight together (unconditional loads from clamped addresses;
+    //         columns left of the cost region were never written: masked below) ----
+    const int xs = xbase + t;
+    const bool src_in = xs >= V3D_D && xs < W;
+    const int xsc = min(max(xs, 0), W - 1);
+    uint32_t wv[NR];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        int ty, tx, x; size_t rowo;
-        tile_xy(it, ty, tx, x, rowo);
-        d1v[it] = dispw[rowo + x];
-    }
+    for (int r = 0; r < NR; r++) wv[r] = wta[fo + (size_t)min(max(y0 - 1 + r, 0), H - 1) * W + xsc];   // replicated image border
+    for (int i = t; i < NR * (LRM_NT + 3); i += 256) (&sD2[0][0])[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- 2. records -> LDS, keys -> min-scatter at target x - d ----
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        int ty, tx, x; size_t rowo;
-        tile_xy(it, ty, tx, x, rowo);
-        const int d1 = d1v[it];
-        const int xa = x - (d1 >> 4), xb = x - ((d1 + 15) >> 4);
-        kav[it] = d2key[rowo + min(max(xa, 0), W - 1)];
-        kbv[it] = d2key[rowo + min(max(xb, 0), W - 1)];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        int ty, tx, x; size_t rowo;
-        if (!tile_xy(it, ty, tx, x, rowo)) continue;
-        int d1 = d1v[it];
-        if (x < V3D_D) d1 = V3D_INVALID16;
-        else if (d1 != V3D_INVALID16) {                                        // lr_checked(), on the values fetched above
-            const int da = d1 >> 4, db = (d1 + 15) >> 4;
-            const int xa = x - da, xb = x - db;
-            bool bad = true;
-            if (xa >= 0 && xa < W) bad = bad && (kav[it] != 0xFFFFFFFFu) && (abs(63 - (int)(kav[it] & 63u) - da) > d12); else bad = false;
-            if (xb >= 0 && xb < W) bad = bad && (kbv[it] != 0xFFFFFFFFu) && (abs(63 - (int)(kbv[it] & 63u) - db) > d12); else bad = false;
-            if (bad) d1 = V3D_INVALID16;
-        }
-        sT[ty][tx] = (short)d1;
+    for (int r = 0; r < NR; r++) {
+        const uint32_t v = src_in ? wv[r] : 0u;
+        sW[r][t] = v;
+        const int best = (int)(v & 63u), i = t - best;                        // target column xs - best
+        if ((v & 0x1FFC0u) != 0u && i >= 0 && i < LRM_NT) atomicMin(&sD2[r][i], ((v >> 17) << 6) | (uint32_t)(63 - best));
     }
     __syncthreads();
+    // ---- 3. L-R check of the tile + ring (stereosgbm.cpp: both roundings of the disparity must disagree) ----
+    constexpr int NIT = (NR * (LRM_TX + 2) + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int i = t + 256 * it;
+        if (i < NR * (LRM_TX + 2)) {
+            const int ty = i / (LRM_TX + 2), tx = i - ty * (LRM_TX + 2);
+            const int x = min(max(x0 - 1 + tx, 0), W - 1);
+            int d1 = V3D_INVALID16;
+            if (x >= V3D_D) {
+                d1 = wta_d16(sW[ty][x - xbase]);
+                if (d1 != V3D_INVALID16) {
+                    const int da = d1 >> 4, db = (d1 + 15) >> 4;              // x - da, x - db lie in [x - 63, x]: always inside the row
+                    const uint32_t ka = sD2[ty][x - da - xbase], kb = sD2[ty][x - db - xbase];
+                    const bool bad = (ka != 0xFFFFFFFFu) && (abs(63 - (int)(ka & 63u) - da) > d12) &&
+                                     (kb != 0xFFFFFFFFu) && (abs(63 - (int)(kb & 63u) - db) > d12);
+                    if (bad) d1 = V3D_INVALID16;
+                }
+            }
+            sT[ty][tx] = (short)d1;
+        }
+    }
+    __syncthreads();
+    // ---- 4. 3x3 median (19-exchange network), 8 outputs per thread ----
     const int tx = t & (LRM_TX - 1), x = x0 + tx;
     if (x >= W) return;
 #pragma unroll
-    for (int ty = t >> 6; ty < LRM_TY; ty += 4) {
+    for (int ty = t >> 7; ty < LRM_TY; ty += 2) {
         const int y = y0 + ty;
         if (y >= H) break;
+        if (!MED) { out[fo + (size_t)y * W + x] = sT[ty + 1][tx + 1]; continue; }
         int p0 = sT[ty][tx], p1 = sT[ty][tx + 1], p2 = sT[ty][tx + 2], p3 = sT[ty + 1][tx], p4 = sT[ty + 1][tx + 1],
             p5 = sT[ty + 1][tx + 2], p6 = sT[ty + 2][tx], p7 = sT[ty + 2][tx + 1], p8 = sT[ty + 2][tx + 2];
         V3D_SORT2(p1, p2); V3D_SORT2(p4, p5); V3D_SORT2(p7, p8); V3D_SORT2(p0, p1);
@@ -1227,24 +1329,28 @@ struct v3d_sgbm {
     int P1, P2, ftzero, uniq, d12;
     int dpl;                                    // disparities per lane in k_chain (4 or 8)
     uint4* rec;
-    int16_t *C, *S, *dispw, *raw, *med;
-    uint32_t* d2key;
+    int16_t *C, *S;
+    uint32_t* wta;                              // WTA records, one per pixel
     uint32_t* ckpt;                             // k_hfused checkpoints
     unsigned long long* gran;                   // k_vdd edge granules
-    int* vdd_err;
+    size_t gran_bytes;
+    int* vdd_err;                               // [0] time-out counter, [16] workgroup ticket counter (k_vdd)
+    uint32_t vdd_ticket_base;                   // tickets drawn by all launches so far
     uint32_t vdd_seq;
     int vdd_mode;                               // 0 off, 1 on
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
     int cost_band;                              // rows per k_cost workgroup
     int vdd_xcd, cost_xcd, hf_xcd;
-    int vdd_mf4, vdd_mf8;                       // co-residency bound (frames per launch) of each mapping
+    int vdd_mf4, vdd_mf8;                       // frames per launch of each mapping at maxW (reported by get_option)
     int vdd_occ4, vdd_occ8, ncu;                // occupancy query results the bounds are derived from
     int reserve_cus;                            // CUs left to other streams' kernels (e.g. an RCCL collective) when sizing a lock-step launch
+    int vdd_launch_frames;                      // 0 = size launches from the occupancy query; > 0: frames per launch (tests: over-sized launches)
     int vdd_spin_limit;                         // 0 = derive from the row count
     int* err_host;                              // pinned, device-visible: lock-step time-outs seen by k_vdd_guard
     hipEvent_t vdd_done_ev;                     // recorded behind the last lock-step launch of a compute call
     bool vdd_ev_recorded;
     bool hfused;
+    int hsplit;                                 // 1: left->right scan of the horizontal pass as its own launch (k_hscan)
     int32_t* labels;
     size_t bytes;
     // optional per-stage HIP-event timing (v3d_sgbm_profile): events live on the caller's stream
@@ -1280,13 +1386,18 @@ template <typename T> static int ws_alloc(T** p, size_t n, size_t* total)
     return V3D_OK;
 }
 
-// frames one lock-step launch may hold: workgroup slots the occupancy query reports, minus the CUs the host says
-// other streams keep busy (two slots each), with a 10 % margin, over the strips of one frame
-static void vdd_size_launches(v3d_sgbm* h)
+// frames one lock-step launch should hold at cost-region width W1: the workgroup slots the occupancy query reports
+// (minus the CUs the host says other streams keep busy, two slots each) over the strips of one frame.  No safety
+// margin: ticketed workgroups (k_vdd) make an over-sized launch slow, not wrong.
+static int vdd_frames_per_launch(const v3d_sgbm* h, int dpl, int W1)
 {
     const int cus = h->ncu - h->reserve_cus > 0 ? h->ncu - h->reserve_cus : 0;
-    h->vdd_mf4 = (h->vdd_occ4 * cus * 9 / 10) / v3d_cdiv(h->maxW - V3D_D, 64);
-    h->vdd_mf8 = (h->vdd_occ8 * cus * 9 / 10) / v3d_cdiv(h->maxW - V3D_D, 128);
+    return ((dpl == 8 ? h->vdd_occ8 : h->vdd_occ4) * cus) / v3d_cdiv(W1, 16 * dpl);
+}
+static void vdd_size_launches(v3d_sgbm* h)
+{
+    h->vdd_mf4 = vdd_frames_per_launch(h, 4, h->maxW - V3D_D);
+    h->vdd_mf8 = vdd_frames_per_launch(h, 8, h->maxW - V3D_D);
 }
 static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_mf4 >= 1 && h->vdd_mf8 >= 1; }
 
@@ -1297,7 +1408,9 @@ static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_
 //   "vdd_dpl"        0/4/8  k_vdd strip mapping (0 = choose per call from the batch size)
 //   "cost_band"      >= 8 rows per k_cost workgroup
 //   "cost_xcd", "vdd_xcd", "hf_xcd"   1/0  XCD-contiguous workgroup order of that kernel
+//   "hsplit"         1/0  k_hfused's left-to-right scan as its own launch (measured: no gain; kept for A/B)
 //   "reserve_cus"    CUs other streams keep busy while a lock-step pass runs (shrinks the frames per launch)
+//   "vdd_launch_frames"  frames per lock-step launch (0 = from the occupancy query); larger than the chip holds is safe (tickets), slow
 //   "vdd_spin_limit" poll rounds a lane may wait in a lock-step pass (0 = 64 per row + 4096; -1 = test hook: every
 //                    workgroup reports a time-out, which drives the guard / V3D_ERR_LOCKSTEP path deterministically)
 extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
@@ -1308,6 +1421,7 @@ extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
     if (is("lockstep")) { if (value != 0 && value != 1) return bad(); h->vdd_mode = value; }
     else if (is("hfused")) { if (value != 0 && value != 1) return bad(); h->hfused = value != 0; }
     else if (is("chain_dpl")) { if (value != 4 && value != 8) return bad(); h->dpl = value; }
+    else if (is("hsplit")) { if (value != 0 && value != 1) return bad(); h->hsplit = value; }
     else if (is("vdd_dpl")) { if (value != 0 && value != 4 && value != 8) return bad(); h->vdd_dpl = value; }
     else if (is("cost_band")) { if (value < 8 || value > 65536) return bad(); h->cost_band = value; }
     else if (is("cost_xcd")) { if (value != 0 && value != 1) return bad(); h->cost_xcd = value; }
@@ -1315,6 +1429,7 @@ extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
     else if (is("hf_xcd")) { if (value != 0 && value != 1) return bad(); h->hf_xcd = value; }
     else if (is("reserve_cus")) { if (value < 0 || value > h->ncu) return bad(); h->reserve_cus = value; vdd_size_launches(h); }
     else if (is("vdd_spin_limit")) { if (value < -1) return bad(); h->vdd_spin_limit = value; }
+    else if (is("vdd_launch_frames")) { if (value < 0) return bad(); h->vdd_launch_frames = value; }
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
     return V3D_OK;
 }
@@ -1325,6 +1440,7 @@ extern "C" int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* valu
     if (is("lockstep")) *value = vdd_usable(h) ? 1 : 0;
     else if (is("hfused")) *value = h->hfused ? 1 : 0;
     else if (is("chain_dpl")) *value = h->dpl;
+    else if (is("hsplit")) *value = h->hsplit;
     else if (is("vdd_dpl")) *value = h->vdd_dpl;
     else if (is("cost_band")) *value = h->cost_band;
     else if (is("cost_xcd")) *value = h->cost_xcd;
@@ -1332,6 +1448,7 @@ extern "C" int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* valu
     else if (is("hf_xcd")) *value = h->hf_xcd;
     else if (is("reserve_cus")) *value = h->reserve_cus;
     else if (is("vdd_spin_limit")) *value = h->vdd_spin_limit;
+    else if (is("vdd_launch_frames")) *value = h->vdd_launch_frames;
     else if (is("vdd_frames_per_launch_dpl4")) *value = h->vdd_mf4;       // read-only: the co-residency bounds in force
     else if (is("vdd_frames_per_launch_dpl8")) *value = h->vdd_mf8;
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
@@ -1368,24 +1485,23 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         return V3D_ERR_UNSUPPORTED;
     }
     h->dpl = 4;
-    const size_t px = (size_t)maxW * maxH * maxB, vol = (size_t)(maxW - V3D_D) * maxH * V3D_D * maxB;
+    const size_t px = (size_t)maxW * maxH * maxB, vol = vol_frame(maxH, maxW - V3D_D) * maxB;
     h->bytes = 0;
     int rc = 0;
     rc |= ws_alloc(&h->rec, px, &h->bytes);
     rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
-    rc |= ws_alloc(&h->dispw, px, &h->bytes); rc |= ws_alloc(&h->raw, px, &h->bytes); rc |= ws_alloc(&h->med, px, &h->bytes);
-    rc |= ws_alloc(&h->d2key, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
+    rc |= ws_alloc(&h->wta, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
     {   // checkpoints: per frame, per wave (DPL rows), per K-pixel block: 64 lanes x (DPL/2 + 1) dwords
         const int W1m = maxW - V3D_D;
         const size_t c4 = (size_t)v3d_cdiv(maxH, 4) * v3d_cdiv(W1m, 16) * 64 * 3, c8 = (size_t)v3d_cdiv(maxH, 8) * v3d_cdiv(W1m, 8) * 64 * 5;
         rc |= ws_alloc(&h->ckpt, (c4 > c8 ? c4 : c8) * maxB, &h->bytes);
     }
-    h->hfused = true;
+    h->hfused = true; h->hsplit = V3D_X_SPLIT;
     {
         h->vdd_dpl = 0;
         const int nstrips_max = v3d_cdiv(maxW - V3D_D, 64);          // granule ring sized for the narrower strips
         const size_t ng = (size_t)maxB * nstrips_max * 2 * VDD_RING * VDD_GRAN;
-        rc |= ws_alloc(&h->gran, ng, &h->bytes);
+        rc |= ws_alloc(&h->gran, ng, &h->bytes); h->gran_bytes = ng * sizeof(unsigned long long);
         rc |= ws_alloc(&h->vdd_err, 64, &h->bytes);
         if (!rc) { (void)hipMemset(h->gran, 0, ng * sizeof(unsigned long long)); (void)hipMemset(h->vdd_err, 0, 64 * sizeof(int)); }
         h->err_host = nullptr;
@@ -1393,9 +1509,9 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         if (h->err_host) *h->err_host = 0;
         h->vdd_done_ev = nullptr; h->vdd_ev_recorded = false;
         if (!rc && hipEventCreateWithFlags(&h->vdd_done_ev, hipEventDisableTiming) != hipSuccess) { h->vdd_done_ev = nullptr; rc = 1; }
-        h->vdd_seq = 1;
+        h->vdd_seq = 1; h->vdd_ticket_base = 0;
         h->vdd_mode = 1;                                  // lock-step pass on; option "lockstep" = 0 falls back to three k_chain launches
-        h->reserve_cus = 0; h->vdd_spin_limit = 0;
+        h->reserve_cus = 0; h->vdd_spin_limit = 0; h->vdd_launch_frames = 0;
         // all strips of a launch must be resident together: bound frames per launch by the occupancy query, with margin
         int b4 = 0, b8 = 0, ncu = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, k_vdd<4, true>, 1024, 0);
@@ -1415,7 +1531,7 @@ extern "C" void v3d_sgbm_destroy(v3d_sgbm* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = { h->rec, h->C, h->S, h->dispw, h->raw, h->med, h->d2key, h->labels, h->ckpt, h->gran, h->vdd_err };
+    void* ptrs[] = { h->rec, h->C, h->S, h->wta, h->labels, h->ckpt, h->gran, h->vdd_err };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
     if (h->vdd_done_ev) (void)hipEventDestroy(h->vdd_done_ev);
@@ -1454,15 +1570,24 @@ static int check_geometry(const v3d_sgbm* h, int n, int W, int H, int pitch)
 // 8 per lane (128-column strips: ~30 % fewer instructions per element, twice the frames per launch)
 static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t st)
 {
-    const int dpl = h->vdd_dpl ? h->vdd_dpl : (n <= h->vdd_mf4 ? 4 : 8);
-    const int mf = dpl == 8 ? h->vdd_mf8 : h->vdd_mf4;
-    for (int f0 = 0; f0 < n; f0 += mf) {
+    // sized from THIS call's width (a handle made for 4K frames holds more 1080p frames per launch)
+    const int mf4 = vdd_frames_per_launch(h, 4, W1), mf8 = vdd_frames_per_launch(h, 8, W1);
+    const int dpl = h->vdd_dpl ? h->vdd_dpl : (n <= mf4 ? 4 : 8);
+    const int mf = h->vdd_launch_frames > 0 ? h->vdd_launch_frames : dpl == 8 ? (mf8 > 0 ? mf8 : 1) : (mf4 > 0 ? mf4 : 1);
+    const int nl = v3d_cdiv(n, mf), per = v3d_cdiv(n, nl);           // equal shares: two launches of 20, not 34 + 6
+    for (int f0 = 0; f0 < n; f0 += per) {
         VddArgs v;
-        const int nf = n - f0 < mf ? n - f0 : mf;
-        v.C = h->C + (size_t)f0 * H * W1 * V3D_D; v.S = h->S + (size_t)f0 * H * W1 * V3D_D;
+        const int nf = n - f0 < per ? n - f0 : per;
+        v.C = h->C + (size_t)f0 * vol_frame(H, W1); v.S = h->S + (size_t)f0 * vol_frame(H, W1);
         v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
-        v.seq = (h->vdd_seq++) & 0xFFFFFu; if (v.seq == 0) v.seq = (h->vdd_seq++) & 0xFFFFFu;
+        v.seq = (h->vdd_seq++) & 0xFFFFFu;
+        if (v.seq == 0) {                                   // the 20-bit launch sequence wrapped: sweep the stale tags (once per 2^20 launches)
+            (void)hipMemsetAsync(h->gran, 0, h->gran_bytes, st);
+            v.seq = (h->vdd_seq++) & 0xFFFFFu;
+        }
         v.gran = h->gran; v.err = h->vdd_err; v.xcd = h->vdd_xcd;
+        v.ticket = reinterpret_cast<uint32_t*>(h->vdd_err + 16); v.ticket_base = h->vdd_ticket_base;
+        h->vdd_ticket_base += (uint32_t)(v.nstrips * nf);
         v.spin_limit = h->vdd_spin_limit != 0 ? h->vdd_spin_limit : VDD_SPIN_PER_ROW * H + VDD_SPIN_SLACK;
         const dim3 grid(v.nstrips * nf), block(1024);
         if (dpl == 8) { if (rev) hipLaunchKernelGGL((k_vdd<8, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<8, false>), grid, block, 0, st, v); }
@@ -1505,8 +1630,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
 
     ChainArgs a;
     a.C = h->C; a.S = h->S; a.W1 = W1; a.H = H; a.W = W; a.nframes = n; a.P1 = h->P1; a.P2 = h->P2; a.uniq = h->uniq;
-    a.dispw = h->dispw; a.d2key = h->d2key; a.xcd = h->hf_xcd;
-    V3D_HIP_CHECK(hipMemsetAsync(h->d2key, 0xFF, (size_t)px * n * sizeof(uint32_t), st));
+    a.wta = h->wta; a.xcd = h->hf_xcd;
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
     const bool use_vdd = vdd_usable(h) && H < 4095;
     if (use_vdd) {
@@ -1543,21 +1667,27 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     } else { prof_mark(h, ST_D1R, st); prof_mark(h, ST_D3R, st); }
     prof_mark(h, ST_H4_WTA, st);
     if (h->hfused) {                                    // r0 + r4 + WTA tail in one launch
-        if (h->dpl == 4) hipLaunchKernelGGL(k_hfused<4>, dim3(v3d_cdiv(v3d_cdiv(H, 4) * n, 4)), dim3(256), 0, st, a, h->ckpt);
-        else hipLaunchKernelGGL(k_hfused<8>, dim3(v3d_cdiv(v3d_cdiv(H, 8) * n, 4)), dim3(256), 0, st, a, h->ckpt);
+        const dim3 g4(v3d_cdiv(v3d_cdiv(H, 4) * n, 4)), g8(v3d_cdiv(v3d_cdiv(H, 8) * n, 4));
+        if (h->hsplit) {
+            if (h->dpl == 4) { hipLaunchKernelGGL(k_hscan<4>, g4, dim3(256), 0, st, a, h->ckpt); hipLaunchKernelGGL((k_hfused<4, 2>), g4, dim3(256), 0, st, a, h->ckpt); }
+            else { hipLaunchKernelGGL(k_hscan<8>, g8, dim3(256), 0, st, a, h->ckpt); hipLaunchKernelGGL((k_hfused<8, 2>), g8, dim3(256), 0, st, a, h->ckpt); }
+        } else {
+            if (h->dpl == 4) hipLaunchKernelGGL((k_hfused<4, 3>), g4, dim3(256), 0, st, a, h->ckpt);
+            else hipLaunchKernelGGL((k_hfused<8, 3>), g8, dim3(256), 0, st, a, h->ckpt);
+        }
     } else
         launch_chain<true, -1, false, 2>(h, a, st);     // r4: (x+1, y), + WTA tail
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_LRCHECK, st);
     if (last_stage == 2) {
-        hipLaunchKernelGGL(k_lrcheck, dim3(v3d_cdiv(W, 256), H, n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, out);
+        hipLaunchKernelGGL(k_lrcheck_median<false>, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->wta, W, H, h->d12, out);
         if (use_vdd) hipLaunchKernelGGL(k_vdd_guard, dim3(256), dim3(256), 0, st, h->vdd_err, h->err_host, out, (size_t)px * n);
         V3D_LAUNCH_CHECK();
         prof_mark(h, ST_MEDIAN, st);
         return V3D_OK;
     }
     prof_mark(h, ST_MEDIAN, st);
-    hipLaunchKernelGGL(k_lrcheck_median, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->dispw, h->d2key, W, H, h->d12, out);
+    hipLaunchKernelGGL(k_lrcheck_median<true>, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->wta, W, H, h->d12, out);
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_SPECKLE, st);
     if (h->prm.speckleWindowSize > 0) {

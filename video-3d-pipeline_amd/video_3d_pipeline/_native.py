@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "libv3d_hip.so")   # override: experiment builds (tools/)
+_LIB_PATH = os.path.join(_HERE, "libv3d_hip.so")
 _lib = None
 
 # every symbol include/v3d_hip.h declares
@@ -48,6 +48,15 @@ class SgbmParams(C.Structure):
 
 def lib_path():
     return _LIB_PATH
+
+
+def use_library(path):
+    """load another build of libv3d_hip.so instead of the in-tree one (development tools only -- tools/envopts.py; the
+    product never calls this and reads no environment variable).  Must come before the first lib()."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise NativeError("use_library() after the library was loaded")
+    _LIB_PATH = os.path.abspath(path)
 
 
 def lib():
