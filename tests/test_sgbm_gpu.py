@@ -386,9 +386,10 @@ def test_reserved_cus_shrink_the_lockstep_launch(native, oracle):
 
 
 def test_oversized_lockstep_launch_waits_instead_of_deadlocking(native, oracle):
-    """k_vdd workgroups draw (frame, strip) tickets in residency order, so a launch with more workgroups than the chip
-    holds (here 96 frames x 8 strips = 768 > 2 x 256 slots, forced with vdd_launch_frames) runs whole frames first and the
-    rest as slots free up: no time-out, the oracle's bits.  (Rounds 1-2 needed every workgroup of a launch resident.)"""
+    """only the strips of ONE frame must be co-resident, and workgroups are dispatched in blockIdx order: a launch with
+    more workgroups than the chip holds (here 96 frames x 8 strips = 768 > 2 x 256 slots, forced with vdd_launch_frames)
+    runs whole frames first and the rest as slots free up: no time-out, the oracle's bits.  (Rounds 1-2 sized every
+    launch 10 % below the occupancy bound and never let one exceed it.)"""
     import torch
     W, H, n, nd = 64 + 1000, 48, 96, 3
     pairs = [textured_pair(W, H, seed=300 + i) for i in range(nd)]

@@ -778,13 +778,15 @@ __global__ __launch_bounds__(256, 8) void k_hscan(ChainArgs a, uint32_t* __restr
 //     (relaxed agent-scope atomic stores / loads: sc1, served by L2, no fences -- MI355X_MICROARCH
 //     "handoff-1to1"), tag = (call sequence << 12) | (row + 1), 4-row ring per strip edge (stays in L2).
 // The coupling is bidirectional (strip k waits for k-1 AND k+1), so the strips of ONE FRAME must be co-resident;
-// frames are independent.  A workgroup therefore takes its (frame, strip) from a TICKET drawn when it starts running
-// (one atomicAdd), not from blockIdx: tickets are handed out in residency order, so the resident workgroups always
-// hold the lowest tickets = whole frames plus at most one partial frame, and a partial frame merely waits (bounded
-// spin) until finished frames free slots for its remaining strips.  A launch larger than the chip -- or a chip that
-// has lost slots to another tenant -- slows down instead of dead-locking; the host still sizes launches to the
-// occupancy query (no margin needed) because a waiting partial frame costs a whole extra pass.  Every spin is
-// bounded and trips an error flag instead of hanging.
+// frames are independent.  Workgroups are dispatched in blockIdx order (per XCD, each XCD taking every 8th), so the
+// resident set is always a prefix of the grid = whole frames plus at most one partial frame per XCD skew, and a
+// partial frame merely waits (bounded spin) until finished frames free slots for its remaining strips: a launch
+// larger than the chip -- or a chip that has lost slots to another tenant -- slows down instead of dead-locking
+// (tests: a 768-workgroup launch on 512 slots).  The host still sizes launches to the occupancy query because a
+// waiting partial frame costs a whole extra pass.  Every spin is bounded and trips an error flag instead of hanging.
+// (Round 3, measured: drawing (frame, strip) from a ticket at workgroup start -- residency order by construction --
+//  scatters neighbour strips over the XCDs and costs 3.38 -> 4.56 ms per 30 frames, like the XCD-contiguous order below;
+//  the hardware's own blockIdx -> XCD round-robin, neighbours on adjacent XCDs, is the fast placement.)
 // ------------------------------------------------------------------------------------------------
 #define VDD_RING 4
 #define VDD_GRAN 34                      // granules per edge per row: 32 data dwords + delta (+1 pad)
@@ -801,8 +803,6 @@ struct VddArgs {
     uint32_t seq;
     int spin_limit;                     // poll rounds a lane may spend waiting over the whole pass
     unsigned long long* gran;           // [frame][strip][2 dirs][VDD_RING][VDD_GRAN]
-    uint32_t* ticket;                   // running counter of started workgroups (all launches of the handle)
-    uint32_t ticket_base;               // its value before this launch
     int* err;
     int xcd;                            // 1: XCD-contiguous strip order.  Measured slower (3.48 -> 4.58 ms per 30 frames): off
 };
@@ -849,14 +849,10 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     __shared__ Vec sL3[2][PXS + 2][LPP];
     __shared__ uint2 sDl[2][PXS + 2];
 
-    __shared__ uint32_t sTicket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave index as an SGPR: edge-wave branches stay scalar
     const int px = wv * PPW + lane / LPP, dl = lane % LPP;      // pixel inside the strip, disparity group
-    if (tid == 0) sTicket = atomicAdd(a.ticket, 1u) - a.ticket_base;      // residency order (see above); wraps with the counter
-    __syncthreads();
-    const uint32_t tk = __builtin_amdgcn_readfirstlane(sTicket);
-    const int vb = a.xcd ? (int)xcd_linear(tk, gridDim.x) : (int)tk;
+    const int vb = a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int frame = vb / a.nstrips, strip = vb - frame * a.nstrips;
     const int W1 = a.W1, H = a.H;
     const int x = strip * PXS + px;
@@ -1334,8 +1330,7 @@ struct v3d_sgbm {
     uint32_t* ckpt;                             // k_hfused checkpoints
     unsigned long long* gran;                   // k_vdd edge granules
     size_t gran_bytes;
-    int* vdd_err;                               // [0] time-out counter, [16] workgroup ticket counter (k_vdd)
-    uint32_t vdd_ticket_base;                   // tickets drawn by all launches so far
+    int* vdd_err;
     uint32_t vdd_seq;
     int vdd_mode;                               // 0 off, 1 on
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
@@ -1388,7 +1383,7 @@ template <typename T> static int ws_alloc(T** p, size_t n, size_t* total)
 
 // frames one lock-step launch should hold at cost-region width W1: the workgroup slots the occupancy query reports
 // (minus the CUs the host says other streams keep busy, two slots each) over the strips of one frame.  No safety
-// margin: ticketed workgroups (k_vdd) make an over-sized launch slow, not wrong.
+// margin: an over-sized launch is slow, not wrong (k_vdd: in-order dispatch keeps whole frames resident).
 static int vdd_frames_per_launch(const v3d_sgbm* h, int dpl, int W1)
 {
     const int cus = h->ncu - h->reserve_cus > 0 ? h->ncu - h->reserve_cus : 0;
@@ -1410,7 +1405,7 @@ static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_
 //   "cost_xcd", "vdd_xcd", "hf_xcd"   1/0  XCD-contiguous workgroup order of that kernel
 //   "hsplit"         1/0  k_hfused's left-to-right scan as its own launch (measured: no gain; kept for A/B)
 //   "reserve_cus"    CUs other streams keep busy while a lock-step pass runs (shrinks the frames per launch)
-//   "vdd_launch_frames"  frames per lock-step launch (0 = from the occupancy query); larger than the chip holds is safe (tickets), slow
+//   "vdd_launch_frames"  frames per lock-step launch (0 = from the occupancy query); larger than the chip holds is safe, slow
 //   "vdd_spin_limit" poll rounds a lane may wait in a lock-step pass (0 = 64 per row + 4096; -1 = test hook: every
 //                    workgroup reports a time-out, which drives the guard / V3D_ERR_LOCKSTEP path deterministically)
 extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
@@ -1509,7 +1504,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         if (h->err_host) *h->err_host = 0;
         h->vdd_done_ev = nullptr; h->vdd_ev_recorded = false;
         if (!rc && hipEventCreateWithFlags(&h->vdd_done_ev, hipEventDisableTiming) != hipSuccess) { h->vdd_done_ev = nullptr; rc = 1; }
-        h->vdd_seq = 1; h->vdd_ticket_base = 0;
+        h->vdd_seq = 1;
         h->vdd_mode = 1;                                  // lock-step pass on; option "lockstep" = 0 falls back to three k_chain launches
         h->reserve_cus = 0; h->vdd_spin_limit = 0; h->vdd_launch_frames = 0;
         // all strips of a launch must be resident together: bound frames per launch by the occupancy query, with margin
@@ -1586,8 +1581,6 @@ static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t 
             v.seq = (h->vdd_seq++) & 0xFFFFFu;
         }
         v.gran = h->gran; v.err = h->vdd_err; v.xcd = h->vdd_xcd;
-        v.ticket = reinterpret_cast<uint32_t*>(h->vdd_err + 16); v.ticket_base = h->vdd_ticket_base;
-        h->vdd_ticket_base += (uint32_t)(v.nstrips * nf);
         v.spin_limit = h->vdd_spin_limit != 0 ? h->vdd_spin_limit : VDD_SPIN_PER_ROW * H + VDD_SPIN_SLACK;
         const dim3 grid(v.nstrips * nf), block(1024);
         if (dpl == 8) { if (rev) hipLaunchKernelGGL((k_vdd<8, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_vdd<8, false>), grid, block, 0, st, v); }

@@ -69,6 +69,25 @@ class HipStereoBackend:
         matcher.set_lockstep(False)
         return False
 
+    def compute_batch_size(self, W: int, H: int, requested: int) -> int:
+        """frames per device pass of the streaming path (process_video_sbs).  The caller's batch_size is list chunking
+        in the reference (depth.py:448-461); here a pass should fill one lock-step SGM launch -- two workgroup slots per
+        CU over the 128-column strips of a frame, 34 frames at 1080p -- because a smaller pass leaves CUs idle (batch 8:
+        0.58 ms per frame, batch 34: 0.36).  Bounded by free HBM: the matcher's workspace is ~290 B per pixel."""
+        torch = self.torch
+        props = torch.cuda.get_device_properties(self.device)
+        strips = max(1, -(-(W - 64) // 128))
+        fill = max(1, (2 * props.multi_processor_count) // strips)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        per_frame = 290 * W * H + 16 * W * H                     # workspace + staging / result tensors of this class
+        fit = max(1, int(0.5 * free) // per_frame)
+        if self._matcher is not None:                            # the workspace already allocated is not "free"
+            fit = max(fit, self._geom[2])
+        n = min(fill, fit)
+        if requested > n:                                        # a caller asking for more gets whole launches
+            n = min((requested // fill) * fill or requested, fit)
+        return max(1, n)
+
     def split_sbs(self, sbs_frame: np.ndarray, unsqueeze: bool):
         d = self.native.to_device(sbs_frame, self.device)
         L, R = self.native.split_sbs(d, unsqueeze)
@@ -149,11 +168,17 @@ class HipStereoBackend:
             if matcher.sync_errors():
                 raise RuntimeError("SGM kernels report time-outs with the lock-step pass off: device fault")
         monos = None
+        out = self._staging("depth", (n, H, ow), torch.float32, False)
         if mono_provider is not None:
-            lefts = [nat.split_sbs(dev[i], unsqueeze)[0].flip(-1).cpu().numpy() for i in range(n)]     # left view, RGB (depth.py:274)
-            monos = mono_provider(lefts)
-        depth = self._depth_from(disp, monos, self._staging("depth", (n, H, ow), torch.float32, False))
-        return depth
+            # a failing provider (DPT forward out of memory, bad shape ...) must not abort the clip -- nor, in a sharded run,
+            # leave the other ranks waiting in the final barrier: warn and continue stereo-only like depth.py:367-369
+            try:
+                lefts = [nat.split_sbs(dev[i], unsqueeze)[0].flip(-1).cpu().numpy() for i in range(n)]     # left view, RGB (depth.py:274)
+                monos = mono_provider(lefts)
+                return self._depth_from(disp, monos, out)
+            except Exception as e:
+                print(f"    Warning: Neural guidance failed, using stereo only: {e}")
+        return self._depth_from(disp, None, out)
 
     def depth_to_host(self, depth) -> np.ndarray:
         """device float32 [n,H,W] -> NumPy through a pinned buffer"""
@@ -381,6 +406,12 @@ class HybridStereoDepthExtractor:
         sharding.require_initialized(world)                  # WORLD_SIZE > 1 without a process group would race the cache dir
         processed_count = 0
         batch, batch_idx = [], []
+        # frames per device pass: decoupled from batch_size (which the reference only uses to chunk its frame list,
+        # depth.py:448-461) -- a pass fills one lock-step SGM launch whatever the caller's chunk size is
+        ow = video_info['width'] if self.unsqueeze_sbs else video_info['width'] // 2
+        sizer = getattr(self.backend, "compute_batch_size", None)
+        pass_frames = sizer(ow, video_info['height'], self.batch_size) if sizer else self.batch_size
+        self.last_pass_frames = pass_frames
         provider = self._guidance_provider()
         # PNG compression (zlib) costs ~20 ms per 1080p map on one core, the GPU path 0.5 ms: the maps of a batch go to
         # a bounded pool of writer threads and compress while the next batch is decoded and computed
@@ -409,7 +440,7 @@ class HybridStereoDepthExtractor:
                 decoded += 1
                 batch.append(frame)
                 batch_idx.append(rank + k * world)
-                if len(batch) == self.batch_size:
+                if len(batch) == pass_frames:
                     flush()
             flush()
         self.last_decoded_frames = decoded

@@ -91,25 +91,34 @@ def total(value: int) -> int:
     return int(t.item())
 
 
+class GuideExchangeAborted(RuntimeError):
+    """the root of the guide exchange failed while decoding; raised by take() on every rank"""
+
+
 class GuideRoundExchange:
     """The one collective of the path: rank `src` decodes a round of `world` 4K guide frames, one broadcast
     hands the round to every rank, rank r keeps frame r.
 
     * the luma never leaves the device on the root: `post` copies device tensors into the round buffer;
     * persistent, double-buffered `[world*H*W + 16]` uint8 round buffers -- no allocation per round;
-    * ONE collective per round: which frames of the round exist (ragged end of the clip) travels in the 16 trailing
-      bytes of the same buffer;
+    * ONE collective per round: which frames of the round exist (ragged end of the clip, or a decoder that ends before
+      the container's frame count) travels in the 16 trailing bytes of the same buffer, and so does an ABORT flag:
+      a root whose decoder fails posts an aborted round, every rank's `take()` raises `GuideExchangeAborted`, nobody
+      is left blocked in the collective;
     * the collective runs on a side stream, so `post(round r+1)` overlaps the compute of round r; `take()` makes the
       current stream wait for the oldest posted round and returns this rank's frame (a private copy) or None.
     On the CPU (`gloo` rehearsals) the same calls run synchronously."""
 
-    META = 16
+    META = 16                  # trailing bytes: validity bitmap in bytes 0..14 (120 ranks), abort flag in byte 15
+    ABORT = 15
 
     def __init__(self, shape, device, src=0, depth=2):
         import torch
         import torch.distributed as dist
         self.rank, self.world = rank_world()
         require_initialized(self.world)
+        if self.world > 8 * self.ABORT:
+            raise ValueError(f"world {self.world} too large for the {8 * self.ABORT}-bit validity bitmap")
         self.H, self.W = int(shape[0]), int(shape[1])
         self.device = torch.device(device)
         self.src, self.depth = src, depth
@@ -123,9 +132,10 @@ class GuideRoundExchange:
         self._posted = 0
         self._dist = dist
 
-    def post(self, round_frames=None):
+    def post(self, round_frames=None, abort=False):
         """enqueue one round.  On `src`: a list of up to `world` entries, each a HxW uint8 device tensor / NumPy array or
-        None (no such frame); other ranks pass nothing."""
+        None (no such frame); other ranks pass nothing.  abort=True (on `src`): the round carries no frames and makes
+        every rank's take() raise."""
         import torch
         slot = self._posted % self.depth
         self._posted += 1
@@ -136,8 +146,9 @@ class GuideRoundExchange:
             cur.wait_event(self._free_ev[slot])
             self._side.wait_event(self._free_ev[slot])
         if self.rank == self.src:
-            frames = list(round_frames or [])[:self.world]
+            frames = [] if abort else list(round_frames or [])[:self.world]
             valid = np.zeros(self.META, np.uint8)
+            valid[self.ABORT] = 1 if abort else 0
             view = buf[:n].view(self.world, self.H, self.W)
             for i, f in enumerate(frames):
                 if f is None:
@@ -147,8 +158,6 @@ class GuideRoundExchange:
                     raise ValueError(f"guide frame {i}: expected uint8 {self.H}x{self.W}, got {t.dtype} {tuple(t.shape)}")
                 view[i].copy_(t, non_blocking=True)
                 valid[i // 8] |= 1 << (i % 8)
-            if self.world > 8 * self.META:
-                raise ValueError("world too large for the validity bitmap")
             buf[n:].copy_(torch.from_numpy(valid), non_blocking=False)
             if self.cuda:
                 e = torch.cuda.Event()
@@ -177,6 +186,8 @@ class GuideRoundExchange:
             torch.cuda.current_stream(self.device).wait_event(ev)
         else:
             meta = buf[n:].numpy()
+        if int(meta[self.ABORT]):
+            raise GuideExchangeAborted(f"rank {self.src} aborted the guide exchange (its decoder failed)")
         if not (int(meta[self.rank // 8]) >> (self.rank % 8)) & 1:
             return None
         out = buf[:n].view(self.world, self.H, self.W)[self.rank].clone()

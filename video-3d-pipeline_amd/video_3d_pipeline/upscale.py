@@ -93,38 +93,61 @@ class SimpleDepthUpscaler:
         frames_dir.mkdir(parents=True, exist_ok=True)
         n = len(depth_files)
         g0 = max(int(guide_start_frame), 0)
-        n_guides = 0
+        # The DECODER decides how many guide frames exist; the container's frame count is only a hint (cv2's
+        # CAP_PROP_FRAME_COUNT and duration * fps are both unreliable).  A clip that ends early degrades the remaining
+        # depth frames to a flat guide (plain smoothing upsample) with a warning; one that runs longer is simply used.
+        n_hint = None
         if video_4k_path:
             info = get_video_info(video_4k_path)
-            if not info:
-                raise ValueError(f"Could not read video info: {video_4k_path}")
-            total = info.get('frames', 0) or int(info['duration'] * info['fps'])
-            n_guides = max(0, min(n, total - g0))     # depth frames [0, n_guides) have a 4K frame; the rest are guided flat
+            if info:
+                total = info.get('frames', 0) or int(info['duration'] * info['fps'])
+                n_hint = max(0, min(n, total - g0))
+            else:
+                print(f"Warning: could not read video info of {video_4k_path}; decoding it anyway")
         # the guide video is decoded ONCE, by rank 0 (one rank: directly into the filter; several: into the round exchange)
-        guides = iter_frames(video_4k_path, g0, n_guides) if (n_guides and rank == 0) else None
+        guides = iter_frames(video_4k_path, g0, n) if (video_4k_path and rank == 0) else None
+        decoded = [0, False]                                  # rank 0: guide frames delivered so far, decoder ended
 
         def next_luma():
             """rank 0: the next guide frame as a device luma tensor (the BGR frame crosses PCIe once, the luma stays on
-            the device); raises if the decoder ends before the frame count the container promised"""
+            the device), or None once the decoder has ended"""
+            if decoded[1]:
+                return None
             f = next(guides, None)
             if f is None:
-                raise RuntimeError(f"4K guide video ended early: {video_4k_path}")
+                decoded[1] = True
+                if n_hint is not None and decoded[0] < n_hint:
+                    print(f"Warning: 4K guide video ended after {decoded[0]} frames (container promised {n_hint}); "
+                          f"depth frames from {decoded[0]} on are upsampled with a flat guide")
+                return None
+            decoded[0] += 1
             return self.backend.to_luma(f)
 
         exchange = None
-        if world > 1 and n_guides:
+        if world > 1 and video_4k_path:
             exchange = sharding.GuideRoundExchange((target_height, target_width), self.backend.device)
 
         def post_round(base):
-            """rank 0 decodes the guide frames of depth frames base .. base+world-1 and posts the round (one collective)"""
-            if base >= n_guides:
+            """rank 0 decodes the guide frames of depth frames base .. base+world-1 and posts the round (one collective).
+            Every rank posts the same ceil(n / world) rounds -- the count depends on the depth files only, which all
+            ranks see; what the decoder really delivered travels in the round's validity bitmap.  A decoder failure on
+            rank 0 is posted as an aborted round first, so the other ranks raise instead of waiting in the collective."""
+            if base >= n:
                 return False
-            frames = [next_luma() if base + r < n_guides else None for r in range(world)] if rank == 0 else None
+            if rank != 0:
+                exchange.post()
+                return True
+            try:
+                frames = [next_luma() if base + r < n else None for r in range(world)]
+            except Exception:
+                exchange.post(abort=True)
+                raise
             exchange.post(frames)
             return True
 
         # this rank's depth maps, decoded a few files ahead on reader threads (PNG inflate is the slowest host step)
         my_depth = prefetch_map(read_png16, [depth_files[i] for i in range(rank, n, world)])
+        flat = 0
         with PngWriterPool() as writers:                  # 4K 16-bit PNGs: ~80 ms of zlib each, compressed off the main thread
             posted = post_round(0) if exchange is not None else False
             for base in range(0, n, world):
@@ -135,18 +158,20 @@ class SimpleDepthUpscaler:
                 guide = None
                 if exchange is not None:
                     if posted:
-                        guide = exchange.take()
-                elif i < n_guides:                        # one rank
+                        guide = exchange.take()           # raises GuideExchangeAborted on every rank if rank 0's decoder failed
+                elif guides is not None and i < n:        # one rank
                     guide = next_luma()
                 posted = posted_next
                 if i >= n:
                     continue
                 if guide is None:
-                    if i < n_guides:                      # a frame the 4K video holds must never degrade to plain smoothing
-                        raise RuntimeError(f"no guide frame arrived for depth frame {i} (rank {rank})")
+                    flat += 1
                     guide = self.backend.flat_guide(target_height, target_width)    # beyond the 4K clip: flat guide == plain smoothing upsample
                 d16 = next(my_depth).astype(np.float32)
                 writers.submit(frames_dir / f"depth4k_{i:06d}.png", self.backend.upscale_u16(d16, guide, self.radius, self.eps))
+        self.last_flat_guides = flat
+        if rank == 0 and guides is not None and n_hint is not None and decoded[0] > n_hint:
+            print(f"Note: the 4K video delivered {decoded[0]} guide frames, the container promised {n_hint}")
         sharding.barrier()
 
         if rank == 0:
