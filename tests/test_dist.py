@@ -73,6 +73,98 @@ def _worker(rank, world, port, tmp, clip, backend="gloo", hip=False):
     dist.destroy_process_group()
 
 
+def _world8_worker(rank, world, port):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from video_3d_pipeline import sharding
+    sharding.init_process_group("gloo")
+    H, W = 4, 6
+    dev = torch.device("cpu")
+    for tail in range(1, world):                               # ragged last round of 1 .. 7 frames
+        ex = sharding.GuideRoundExchange((H, W), dev, depth=4)
+        nfr = 3 * world + tail
+        nround = -(-nfr // world)
+
+        def rnd(b):
+            return [np.full((H, W), (3 + b + r) % 251, np.uint8) if b + r < nfr else None for r in range(world)] if rank == 0 else None
+        for k in range(min(3, nround)):                        # three rounds posted ahead of the first take
+            ex.post(rnd(k * world))
+        for k in range(nround):
+            if k + 3 < nround:
+                ex.post(rnd((k + 3) * world))
+            g = ex.take()
+            i = k * world + rank
+            assert (g is not None) == (i < nfr), (tail, k, rank)
+            if g is not None:
+                assert g.dtype == torch.uint8 and tuple(g.shape) == (H, W) and int(g[0, 0]) == (3 + i) % 251 and int(g[-1, -1]) == (3 + i) % 251
+        # the validity bitmap of the last round as it arrived: bits 0 .. tail-1
+        meta = ex._bufs[(nround - 1) % 4][world * H * W:].numpy()
+        assert int(meta[0]) == (1 << tail) - 1 and not meta[1:].any(), (tail, meta)
+    # a failing root: the aborted round makes EVERY rank raise, nobody waits in a collective
+    ex = sharding.GuideRoundExchange((H, W), dev)
+    ex.post([np.zeros((H, W), np.uint8)] * world if rank == 0 else None)
+    assert ex.take() is not None
+    ex.post(abort=True) if rank == 0 else ex.post()
+    with pytest.raises(sharding.GuideExchangeAborted):
+        ex.take()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_guide_exchange_world8_gloo():
+    """the one collective at the world size it is meant for (8 ranks, CPU rehearsal): validity bitmap bytes, every ragged
+    tail 1 .. 7, three rounds posted ahead (depth-4 ring), and the abort flag of a failing root"""
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_world8_worker, args=(8, port), nprocs=8, join=True)
+
+
+def _abort_worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "video-3d-pipeline_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from video_3d_pipeline import sharding, upscale
+    from test_host import OracleUpscaleBackend
+    sharding.init_process_group("gloo")
+    real = upscale.iter_frames
+
+    def broken(path, start, count, **kw):                      # the guide decoder dies after two frames
+        for k, f in enumerate(real(path, start, count, **kw)):
+            if k == 2:
+                raise IOError("decoder lost the stream")
+            yield f
+    upscale.iter_frames = broken
+    up = upscale.SimpleDepthUpscaler(backend=OracleUpscaleBackend())
+    with pytest.raises((IOError, sharding.GuideExchangeAborted)) as ei:
+        up.upscale_depth_maps_ffmpeg(os.path.join(tmp, "d"), 64, 40, os.path.join(tmp, "up.mp4"), video_4k_path=os.path.join(tmp, "guide.npy"))
+    assert isinstance(ei.value, IOError if rank == 0 else sharding.GuideExchangeAborted)
+    dist.barrier()                                             # both ranks got here: nobody hung in the broadcast
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_guide_decoder_failure_raises_on_every_rank(tmp_path):
+    """rank 0's guide decoder failing must not leave the other ranks blocked in the exchange"""
+    sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeline_amd"))
+    from video_3d_pipeline import synthetic as syn
+    from video_3d_pipeline.utils import write_png16
+    d = tmp_path / "d"
+    d.mkdir()
+    rng = np.random.default_rng(5)
+    for i in range(6):
+        write_png16(d / f"depth_{i:06d}.png", rng.integers(0, 65535, (20, 32)).astype(np.uint16))
+    guides = np.stack([np.repeat(syn.guide_frame(32, 20, i)[..., None], 3, axis=2) for i in range(6)])
+    np.save(str(tmp_path / "guide.npy"), guides)
+    port = 29800 + (os.getpid() % 2000)
+    mp.spawn(_abort_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
 def test_round_robin_assignment():
     from video_3d_pipeline import sharding
     assert sharding.my_frames(10, 1, 4) == [1, 5, 9]

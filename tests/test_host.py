@@ -234,6 +234,41 @@ def test_upscaler_flow_with_manifest(tmp_path):
     assert np.abs(q0.astype(np.float64) - np.clip(np.rint(want0), 0, 65535)).max() <= 1
 
 
+def test_guide_count_comes_from_the_decoder_not_the_container(tmp_path, capsys, monkeypatch):
+    """the container's frame count is a hint.  A 4K clip that ends early degrades the remaining depth frames to
+    a flat guide with a warning (no exception at the last round); one that runs longer than promised is simply used."""
+    from video_3d_pipeline import upscale, synthetic as syn
+    from video_3d_pipeline.utils import write_png16, read_png16, get_video_info
+    ddir = tmp_path / "depth_x"
+    ddir.mkdir()
+    rng = np.random.default_rng(1)
+    lows = [(rng.uniform(0, 65535, (20, 32))).astype(np.uint16) for _ in range(3)]
+    for i, a in enumerate(lows):
+        write_png16(ddir / f"depth_{i:06d}.png", a)
+    guides = np.stack([np.repeat(syn.guide_frame(32, 20, i)[..., None], 3, axis=2) for i in range(3)])
+    flat = np.full((40, 64), 128, np.uint8)
+
+    def run(n_in_clip, promised, tag):
+        v4k = tmp_path / f"v_{tag}.npy"
+        np.save(v4k, guides[:n_in_clip])
+        info = dict(get_video_info(str(v4k)), frames=promised)
+        monkeypatch.setattr(upscale, "get_video_info", lambda p: info)
+        up = upscale.SimpleDepthUpscaler(backend=OracleUpscaleBackend())
+        out = up.upscale_depth_maps_ffmpeg(str(ddir), 64, 40, str(tmp_path / f"o_{tag}.mp4"), video_4k_path=str(v4k))
+        fr = json.loads(open(out).read())["frames_dir"]
+        return up, [read_png16(os.path.join(fr, f"depth4k_{i:06d}.png")).astype(np.float64) for i in range(3)]
+
+    def want(i, g):
+        return np.clip(np.rint(O.guided_upscale(lows[i].astype(np.float32), g, 8, 1e-3)), 0, 65535)
+    up, got = run(1, 3, "short")                               # container promises 3, decoder delivers 1
+    assert up.last_flat_guides == 2 and "ended after 1 frames (container promised 3)" in capsys.readouterr().out
+    assert np.abs(got[0] - want(0, O.bgr_to_gray(guides[0]))).max() <= 1
+    assert all(np.abs(got[i] - want(i, flat)).max() <= 1 for i in (1, 2))
+    up, got = run(3, 1, "long")                                # container promises 1, decoder delivers 3: all three used
+    assert up.last_flat_guides == 0 and "delivered 3 guide frames, the container promised 1" in capsys.readouterr().out
+    assert all(np.abs(got[i] - want(i, O.bgr_to_gray(guides[i]))).max() <= 1 for i in range(3))
+
+
 def test_upscale_cli_error_exit(tmp_path, capsys):
     from video_3d_pipeline import upscale
     rc = upscale.main([str(tmp_path), str(tmp_path / "none.mp4")])

@@ -137,6 +137,13 @@ class GuideRoundExchange:
         None (no such frame); other ranks pass nothing.  abort=True (on `src`): the round carries no frames and makes
         every rank's take() raise."""
         import torch
+        # never enter another collective behind an aborted round: the root has left.  The youngest round already posted
+        # must have arrived before the next one is issued (with the usual one-round-ahead pattern it has: take() of the
+        # same round follows at once), and its abort flag is looked at first.
+        if self._pending:
+            pslot, pev = self._pending[-1]
+            if self._round_aborted(pslot, pev):
+                raise GuideExchangeAborted(f"rank {self.src} aborted the guide exchange (its decoder failed)")
         slot = self._posted % self.depth
         self._posted += 1
         buf = self._bufs[slot]
@@ -173,6 +180,13 @@ class GuideRoundExchange:
             self._dist.broadcast(buf, src=self.src)
             ev = None
         self._pending.append((slot, ev))
+
+    def _round_aborted(self, slot, ev):
+        if self.cuda:
+            ev.synchronize()
+            return bool(int(self._meta_host[slot].numpy()[self.ABORT]))
+        n = self.world * self.H * self.W
+        return bool(int(self._bufs[slot][n + self.ABORT]))
 
     def take(self):
         """this rank's frame of the oldest posted round as a private HxW uint8 tensor, or None if the clip had none"""
