@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeli
 import numpy as np, torch
 from video_3d_pipeline import _native as N, synthetic as syn
 import envopts
+envopts.select_variant_lib(N)
 W, H = int(os.environ.get("QB_W", "1920")), int(os.environ.get("QB_H", "1080"))
 B = int(os.environ.get("QB_BATCH", "8"))
 L, R = syn.gray_pair(W, H, 0)

@@ -352,22 +352,34 @@ struct ChainArgs {
     int xcd;                  // k_hfused: XCD-contiguous row-group order (V3D_HF_XCD=1).  Measured 4 % slower: off
 };
 
+// minimum of both halves of `mn` over the LPP lanes of a pixel, returned in BOTH halves.  One v_pk_min_u16 with op_sel
+// swaps the halves against each other (lo = min(lo, hi), hi = min(hi, lo)); a word with equal halves orders like its
+// half as an unsigned 32-bit number, so each butterfly step is ONE v_min_u32 with a DPP operand (packed VOP3P ops cannot
+// take DPP) and the result needs no re-broadcast.  Costs are non-negative 15-bit values.
+template <int LPP>
+__device__ __forceinline__ uint32_t pk_hmin_lanes(uint32_t mn)
+{
+    uint32_t m1;
+    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m1) : "v"(mn));
+    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(1, 0, 3, 2)>(m1));
+    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(2, 3, 0, 1)>(m1));
+    if (LPP >= 8) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_HALF_MIRROR>(m1));
+    if (LPP >= 16) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_MIRROR>(m1));
+    return m1;
+}
+
 // L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta ; returns delta' = min_d L[d] + P2 (both halves)
 template <int NP, int LPP>
 __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t delta, const uint32_t (&c)[NP],
                                                uint32_t (&L)[NP], uint32_t P1pk, uint32_t P2pk, bool first_lane, bool last_lane)
 {
     const uint32_t MAXPK = 0x7FFF7FFFu;
-    uint32_t prev, next;
-    if (LPP < 16) {
-        // several pixels per DPP row: the pixel-edge lanes are patched by a select anyway, so the shift needs no
-        // pre-initialised destination (saves the v_mov of the fill value per shift)
-        prev = dpp_xchg<V3D_DPP_ROW_SHR(1)>(p[NP - 1]); next = dpp_xchg<V3D_DPP_ROW_SHL(1)>(p[0]);
-        prev = first_lane ? MAXPK : prev; next = last_lane ? MAXPK : next;
-    } else {
-        prev = dpp_mov<V3D_DPP_ROW_SHR(1)>(MAXPK, p[NP - 1]);     // one pixel per DPP row: lanes without a source keep the fill
-        next = dpp_mov<V3D_DPP_ROW_SHL(1)>(MAXPK, p[0]);
-    }
+    // d-1 / d+1 across the lanes of a pixel: one v_or_b32 with a DPP operand each.  The pixel's edge lanes OR the
+    // out-of-range fill in (costs are 15-bit, so x | 0x7FFF7FFF is the fill whatever the shift delivered: the neighbour
+    // pixel's lane, or 0 from bound_ctrl where the DPP row ends); the masks are loop-invariant registers.
+    const uint32_t fill_prev = first_lane ? MAXPK : 0u, fill_next = last_lane ? MAXPK : 0u;
+    const uint32_t prev = dpp_xchg<V3D_DPP_ROW_SHR(1)>(p[NP - 1]) | fill_prev;
+    const uint32_t next = dpp_xchg<V3D_DPP_ROW_SHL(1)>(p[0]) | fill_next;
     uint32_t m[NP + 1];
     m[0] = alignbit(p[0], prev, 16);
 #pragma unroll
@@ -376,19 +388,13 @@ __device__ __forceinline__ uint32_t chain_step(const uint32_t (&p)[NP], uint32_t
     uint32_t mn = MAXPK;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+        // C - delta + min(p, n, delta) = C - max(delta - min(p, n), 0): the clamp is the unsigned saturating subtract's
+        // (5 packed ops per pair instead of 6; delta - min(p, n) <= P2 <= C, all operands in [0, 32767))
         uint32_t n = pk_add(pk_min(m[i], m[i + 1]), P1pk);
-        uint32_t t = pk_min(pk_min(p[i], n), delta);
-        L[i] = pk_add(pk_sub(c[i], delta), t);
+        L[i] = pk_sub(c[i], pk_subu_sat(delta, pk_min(p[i], n)));
         mn = pk_min(mn, L[i]);
     }
-    // costs are non-negative: finish the min as an unsigned 32-bit scalar so each butterfly step is ONE
-    // v_min_u32 with a DPP operand (packed VOP3P ops cannot take DPP and would need a v_mov_dpp each)
-    uint32_t m1 = min(mn & 0xFFFFu, mn >> 16);
-    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(1, 0, 3, 2)>(m1));
-    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(2, 3, 0, 1)>(m1));
-    if (LPP >= 8) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_HALF_MIRROR>(m1));
-    if (LPP >= 16) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_MIRROR>(m1));
-    return pk_add(m1 | (m1 << 16), P2pk);
+    return pk_add(pk_hmin_lanes<LPP>(mn), P2pk);
 }
 
 // delta = min_d L[d] + P2 (both halves) recomputed from a path-state vector: lets checkpoints drop the delta word
@@ -398,12 +404,7 @@ __device__ __forceinline__ uint32_t chain_delta(const uint32_t (&p)[NP], uint32_
     uint32_t mn = p[0];
 #pragma unroll
     for (int i = 1; i < NP; i++) mn = pk_min(mn, p[i]);
-    uint32_t m1 = min(mn & 0xFFFFu, mn >> 16);
-    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(1, 0, 3, 2)>(m1));
-    m1 = min(m1, dpp_xchg<V3D_DPP_QUAD(2, 3, 0, 1)>(m1));
-    if (LPP >= 8) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_HALF_MIRROR>(m1));
-    if (LPP >= 16) m1 = min(m1, dpp_xchg<V3D_DPP_ROW_MIRROR>(m1));
-    return pk_add(m1 | (m1 << 16), P2pk);
+    return pk_add(pk_hmin_lanes<LPP>(mn), P2pk);
 }
 
 #define WTA_ROWB 144   // bytes per pixel row in LDS (128 + 16 pad, keeps 16-B alignment)
