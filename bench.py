@@ -9,8 +9,8 @@
 One "step" = one pass of the hot path over one batch of `--batch` synthetic SBS frames (default 30 = what one
 co-resident lock-step k_vdd launch holds at 1080p; the reference's own batch_size is 8, depth.py:27 -- the same path at
 batch 8 is reported under `e2e.batch8` and `extra.batch8_hbm_resident`) already resident in HBM:
-v3d_sbs_to_gray -> v3d_sgbm_compute_batch -> v3d_disp_to_depth -> v3d_guided_upscale against the 4K guide -> float32 4K
-depth in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the only
+v3d_sbs_to_gray -> v3d_sgbm_compute_batch -> v3d_guided_upscale_disp16_batch (depth.py:341/374's `/16` + clamp inside its loads)
+against the 4K guide -> float32 4K depth in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the only
 collective is the 4K guide round from rank 0 (RCCL), double-buffered on a side stream and ordered BEHIND the lock-step
 SGM pass of the step it overlaps (v3d_sgbm_stream_wait_lockstep).  Rank 0 prints ONE JSON line:
 
@@ -172,13 +172,15 @@ class HotPath:
         N, n = self.N, sbs.shape[0]
         N.sbs_to_gray_batch(sbs, True, (self.lg[:n], self.rg[:n]))
         self.matcher.compute(self.lg[:n], self.rg[:n], self.disp[:n])
-        N.disp_to_depth(self.disp[:n], self.depth[:n])
         if not upscale:
+            N.disp_to_depth(self.disp[:n], self.depth[:n])       # configs[1]: the float32 depth map is the output (depth.py:341, 374)
             return
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        N.guided_upscale_batch(self.depth[:n], guides, GF_R, GF_EPS, self.out4k[:n] if out4k is None else out4k)
+        # the filter takes the int16 disparity itself: `/16` and `<= 0 -> 0` happen in its loads, the float32 1080p plane is never
+        # written or re-read (bit-identical to v3d_disp_to_depth + v3d_guided_upscale_batch: tests/test_guided_gpu.py)
+        N.guided_upscale_batch(self.disp[:n], guides, GF_R, GF_EPS, self.out4k[:n] if out4k is None else out4k)
         if timed:
             e1.record()
             self.gf_ev.append((e0, e1))

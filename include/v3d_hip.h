@@ -170,6 +170,13 @@ int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* g
 int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
                              int Whi, int Hhi, size_t guide_stride, int n, int r, float eps, float* out,
                              void* ws, void* stream);
+/* the same filter fed with the matcher's int16 disparity (x16, <= 0 = invalid): depth.py:341 `.astype(float32)/16.0` and
+   depth.py:374 `disparity[disparity <= 0] = 0` happen as the values are loaded, so the stereo-only pipeline
+   (sgbm -> upscale) never writes or re-reads the float32 depth plane.  Bit-identical to v3d_disp_to_depth followed by
+   v3d_guided_upscale_batch.  Frame f at disp16 + f*disp_stride (int16 elements). */
+int v3d_guided_upscale_disp16_batch(const int16_t* disp16, int Wlo, int Hlo, size_t disp_stride, const uint8_t* guide,
+                                    int Whi, int Hhi, size_t guide_stride, int n, int r, float eps, float* out,
+                                    void* ws, void* stream);
 /* BGR [H][W][3] u8 -> luma u8 with the same weights as cvtColor */
 int v3d_bgr_to_gray(const uint8_t* bgr, size_t n_pixels, uint8_t* gray, void* stream);
 

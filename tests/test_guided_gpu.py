@@ -136,3 +136,27 @@ def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, b
     if Wg * Hg <= 700 * 400:
         want = oracle.guided_upscale(depth, guide, r, 1e-3)
         assert _rel_err(one.cpu().numpy().astype(np.float64), want).max() <= RTOL
+
+
+@pytest.mark.parametrize("r,fused,tiled", [(8, 1, 0), (8, 0, 0), (4, 1, 0), (16, 1, 0), (8, 1, 1)])
+def test_disp16_input_equals_depth_input_bit_for_bit(native, r, fused, tiled):
+    """v3d_guided_upscale_disp16_batch applies depth.py:341 `/16` and depth.py:374 `<= 0 -> 0` inside the filter's loads:
+    identical bits to v3d_disp_to_depth followed by v3d_guided_upscale_batch, in every kernel family (fused strips,
+    two sweeps, LDS tiles), invalid (-16) and zero disparities included"""
+    import torch
+    rng = np.random.default_rng(100 + r)
+    disp = rng.integers(-16, 64 * 16, (2, 90, 160)).astype(np.int16)
+    disp[rng.random(disp.shape) < 0.1] = -16
+    disp[:, :, :8] = 0
+    guide = rng.integers(0, 256, (2, 180, 320), dtype=np.uint8)
+    d16, g = native.to_device(disp), native.to_device(guide)
+    try:
+        native.set_option("gf_fused", fused)
+        native.set_option("gf_tiled", tiled)
+        via_depth = native.guided_upscale_batch(native.disp_to_depth(d16), g, r, 1e-3)
+        direct = native.guided_upscale_batch(d16, g, r, 1e-3)
+    finally:
+        native.set_option("gf_fused", 1)
+        native.set_option("gf_tiled", 0)
+    assert torch.equal(direct, via_depth)
+    assert float(direct.abs().max()) > 1.0

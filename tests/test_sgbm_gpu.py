@@ -406,7 +406,7 @@ def test_oversized_lockstep_launch_waits_instead_of_deadlocking(native, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("W,H", [(300, 40), (64, 9), (1, 5), (257, 1), (640, 33)])
+@pytest.mark.parametrize("W,H", [(300, 40), (64, 9), (1, 5), (257, 1), (640, 33), (516, 19), (1920, 17)])
 def test_speckle_run_lists_extremes(native, oracle, W, H):
     """the run-list CCL at its corners: every pixel its own run (a full run list without end marker, > 64 runs per row
     -> several steps of the per-row walkers), one run per row, single-column / single-row images, runs of exactly the

@@ -24,12 +24,19 @@ __device__ __forceinline__ double gf_rcp(double x)
     return r;
 }
 
+// the low-resolution depth comes either as float32 (depth.py's frame-out surface, any provider) or straight as the matcher's
+// int16 disparity x16: then depth.py:341 `/16` and depth.py:374 `<= 0 -> 0` happen in the load (the float map never exists)
+template <typename TD> __device__ __forceinline__ float gf_ld(const TD* p, size_t i);
+template <> __device__ __forceinline__ float gf_ld<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float gf_ld<int16_t>(const int16_t* p, size_t i) { const int d = p[i]; return d > 0 ? (float)d * 0.0625f : 0.f; }
+
 #define GF_TX 64
 #define GF_RUN 8      // outputs per thread along x in the horizontal pass
 #define GF_RMAX 16
 // tile height TY = 4 * RUNY: 16 rows for r <= 8, 8 rows above (keeps the f64 tile inside the 160 KiB LDS)
 
-__device__ __forceinline__ double gf_bilinear(const float* __restrict__ src, int Ws, int Hs, double sx, double sy, int x, int y)
+template <typename TD>
+__device__ __forceinline__ double gf_bilinear(const TD* __restrict__ src, int Ws, int Hs, double sx, double sy, int x, int y)
 {
     const double fx = (x + 0.5) * sx - 0.5, fy = (y + 0.5) * sy - 0.5;
     const double x0f = floor(fx), y0f = floor(fy);
@@ -37,14 +44,14 @@ __device__ __forceinline__ double gf_bilinear(const float* __restrict__ src, int
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int xa = min(max(x0, 0), Ws - 1), xb = min(max(x0 + 1, 0), Ws - 1);
     const int ya = min(max(y0, 0), Hs - 1), yb = min(max(y0 + 1, 0), Hs - 1);
-    const double top = (double)src[(size_t)ya * Ws + xa] * (1.0 - wx) + (double)src[(size_t)ya * Ws + xb] * wx;
-    const double bot = (double)src[(size_t)yb * Ws + xa] * (1.0 - wx) + (double)src[(size_t)yb * Ws + xb] * wx;
+    const double top = (double)gf_ld(src, (size_t)ya * Ws + xa) * (1.0 - wx) + (double)gf_ld(src, (size_t)ya * Ws + xb) * wx;
+    const double bot = (double)gf_ld(src, (size_t)yb * Ws + xa) * (1.0 - wx) + (double)gf_ld(src, (size_t)yb * Ws + xb) * wx;
     return top * (1.0 - wy) + bot * wy;
 }
 
 // NQ_IN planes staged (2), NQ_SUM planes summed (4 in sweep 1: I, p, II, Ip; 2 in sweep 2: a, b)
-template <int SWEEP, int GF_RUNY>
-__global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+template <int SWEEP, int GF_RUNY, typename TD>
+__global__ __launch_bounds__(256) void k_gf(const TD* __restrict__ depth_lo, int Wlo, int Hlo,
                                             const uint8_t* __restrict__ guide, int W, int H, int r, double eps,
                                             double* __restrict__ A, double* __restrict__ B, float* __restrict__ out)
 {
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(256) void k_gf(const float* __restrict__ depth_lo, 
 typedef double v3d_f64x2 __attribute__((ext_vector_type(2)));
 typedef float v3d_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int SWEEP, int RR>
-__global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+template <int SWEEP, int RR, typename TD>
+__global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, int Wlo, int Hlo,
                                              const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
                                              double* __restrict__ A, double* __restrict__ B, float* __restrict__ out,
                                              size_t depth_stride, size_t guide_stride)
@@ -220,9 +227,9 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
         if (SWEEP == 1) {
             q.g = guide[o];
             const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy);
-            const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
-            const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
-            q.a0 = ra[bxa]; q.a1 = ra[bxb]; q.b0 = rb[bxa]; q.b1 = rb[bxb];
+            const TD* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
+            const TD* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
+            q.a0 = gf_ld(ra, bxa); q.a1 = gf_ld(ra, bxb); q.b0 = gf_ld(rb, bxa); q.b1 = gf_ld(rb, bxb);
         } else {
             q.n0 = __builtin_nontemporal_load(A + o); q.n1 = __builtin_nontemporal_load(B + o);
         }
@@ -381,8 +388,8 @@ __global__ __launch_bounds__(256) void k_gfm(const float* __restrict__ depth_lo,
 // bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
 // skips the count reciprocals away from the border (more spills, 2.26 ms), s_setprio for the stage-1 waves (2.21-2.25 ms).
 // ------------------------------------------------------------------------------------------------
-template <int RR, int COLS>
-__global__ __launch_bounds__(2 * COLS, 4) void k_gff(const float* __restrict__ depth_lo, int Wlo, int Hlo,
+template <int RR, int COLS, typename TD>
+__global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ depth_lo, int Wlo, int Hlo,
                                                 const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
                                                 float* __restrict__ out, size_t depth_stride, size_t guide_stride)
 {
@@ -438,9 +445,9 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const float* __restrict__ d
             const size_t o = (size_t)min(max(e, 0), H - 1) * W + gxc;
             q.g = guide[o];
             const double fy = (e + 0.5) * sy - 0.5, y0f = floor(fy);
-            const float* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
-            const float* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
-            q.a0 = ra[bxa]; q.a1 = ra[bxb]; q.b0 = rb[bxa]; q.b1 = rb[bxb];
+            const TD* ra = depth_lo + (size_t)min(max((int)y0f, 0), Hlo - 1) * Wlo;
+            const TD* rb = depth_lo + (size_t)min(max((int)y0f + 1, 0), Hlo - 1) * Wlo;
+            q.a0 = gf_ld(ra, bxa); q.a1 = gf_ld(ra, bxb); q.b0 = gf_ld(rb, bxa); q.b1 = gf_ld(rb, bxb);
             return q;
         };
         RowIn nx[2] = { fetch_row(0), fetch_row(1) };
@@ -642,30 +649,30 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const float* __restrict__ d
     }
 }
 
-template <int RR>
-static void launch_gff(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
+template <int RR, typename TD>
+static void launch_gff(const TD* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
     const int band = g_v3d_opt.gf_band;
     if (g_v3d_opt.gf_cols == 512) {        // 512-column strips, 16 waves, one workgroup per CU: half the strip-halo recompute
         const dim3 grid(v3d_cdiv(W, 512 - 4 * RR), v3d_cdiv(H, band), n);
-        hipLaunchKernelGGL((k_gff<RR, 512>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+        hipLaunchKernelGGL((k_gff<RR, 512, TD>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
         return;
     }
     const dim3 grid(v3d_cdiv(W, 256 - 4 * RR), v3d_cdiv(H, band), n);
-    hipLaunchKernelGGL((k_gff<RR, 256>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gff<RR, 256, TD>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
 }
 
-template <int RR>
-static void launch_gfm(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
+template <int RR, typename TD>
+static void launch_gfm(const TD* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        double* A, double* B, float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
     // band heights (measured sweep, 30 x 4K frames): each band pays 2r warm-up rows; sweep 1 is VALU-bound, sweep 2
     // is bound by its re-reads of the f64 a/b planes
     const int band1 = g_v3d_opt.gf_band1, band2 = g_v3d_opt.gf_band2;
     const dim3 grid1(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band1), n), grid2(v3d_cdiv(W, 256 - 2 * RR), v3d_cdiv(H, band2), n);
-    hipLaunchKernelGGL((k_gfm<1, RR>), grid1, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band1, A, B, out, depth_stride, guide_stride);
-    hipLaunchKernelGGL((k_gfm<2, RR>), grid2, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band2, A, B, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gfm<1, RR, TD>), grid1, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band1, A, B, out, depth_stride, guide_stride);
+    hipLaunchKernelGGL((k_gfm<2, RR, TD>), grid2, dim3(256), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band2, A, B, out, depth_stride, guide_stride);
 }
 
 extern "C" size_t v3d_guided_upscale_ws_bytes(int W, int H)
@@ -681,10 +688,11 @@ static size_t gf_smem(int r, int ns, int ty)
     return sizeof(double) * ((size_t)2 * rows * pitch + (size_t)ns * rows * (GF_TX + 1));
 }
 
-// n frames: frame f at depth_lo + f*depth_stride (floats), guide + f*guide_stride (bytes), out + f*W*H;
+// n frames: frame f at depth_lo + f*depth_stride (elements), guide + f*guide_stride (bytes), out + f*W*H;
 // ws must hold n * v3d_guided_upscale_ws_bytes(W, H)
-extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
-                                        int W, int H, size_t guide_stride, int n, int r, float eps, float* out, void* ws, void* stream)
+template <typename TD>
+static int guided_upscale_batch(const TD* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
+                                int W, int H, size_t guide_stride, int n, int r, float eps, float* out, void* ws, void* stream)
 {
     if (n < 1) { v3d_set_error("bad batch"); return V3D_ERR_ARG; }
     if (!depth_lo || !guide || !out || !ws) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
@@ -707,30 +715,44 @@ extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo,
         return V3D_OK;
     }
     for (int f = 0; f < n; f++) {
-    const float* depth_lo_f = depth_lo + (size_t)f * depth_stride; const uint8_t* guide_f = guide + (size_t)f * guide_stride;
+    const TD* depth_lo_f = depth_lo + (size_t)f * depth_stride; const uint8_t* guide_f = guide + (size_t)f * guide_stride;
     double* A = reinterpret_cast<double*>(ws) + (size_t)f * 2 * W * H; double* B = A + (size_t)W * H; float* out_f = out + (size_t)f * W * H;
     const int ty = r <= 8 ? 16 : 8;
     const dim3 grid(v3d_cdiv(W, GF_TX), v3d_cdiv(H, ty));
     const size_t sm1 = gf_smem(r, 4, ty), sm2 = gf_smem(r, 2, ty);
     if (ty == 16) {
         // above the default dynamic-LDS limit: opt in (160 KiB per CU on gfx950)
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
-        hipLaunchKernelGGL((k_gf<1, 4>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
-        hipLaunchKernelGGL((k_gf<2, 4>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 4, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 4, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
+        hipLaunchKernelGGL((k_gf<1, 4, TD>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        hipLaunchKernelGGL((k_gf<2, 4, TD>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
     } else {
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
-        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
-        hipLaunchKernelGGL((k_gf<1, 2>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
-        hipLaunchKernelGGL((k_gf<2, 2>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<1, 2, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+        V3D_HIP_CHECK(hipFuncSetAttribute((const void*)k_gf<2, 2, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
+        hipLaunchKernelGGL((k_gf<1, 2, TD>), grid, dim3(256), sm1, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
+        hipLaunchKernelGGL((k_gf<2, 2, TD>), grid, dim3(256), sm2, st, depth_lo_f, Wlo, Hlo, guide_f, W, H, r, (double)eps, A, B, out_f);
     }
     }
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
 
+extern "C" int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t depth_stride, const uint8_t* guide,
+                                        int W, int H, size_t guide_stride, int n, int r, float eps, float* out, void* ws, void* stream)
+{
+    return guided_upscale_batch<float>(depth_lo, Wlo, Hlo, depth_stride, guide, W, H, guide_stride, n, r, eps, out, ws, stream);
+}
+
 extern "C" int v3d_guided_upscale(const float* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H,
                                   int r, float eps, float* out, void* ws, void* stream)
 {
-    return v3d_guided_upscale_batch(depth_lo, Wlo, Hlo, 0, guide, W, H, 0, 1, r, eps, out, ws, stream);
+    return guided_upscale_batch<float>(depth_lo, Wlo, Hlo, 0, guide, W, H, 0, 1, r, eps, out, ws, stream);
+}
+
+// the same filter fed with the matcher's int16 disparity (x16, <= 0 invalid): depth.py:341 `/16` and :374 `<= 0 -> 0` are
+// applied as the values are loaded, so the stereo-only pipeline never writes or re-reads the float32 depth plane
+extern "C" int v3d_guided_upscale_disp16_batch(const int16_t* disp16, int Wlo, int Hlo, size_t disp_stride, const uint8_t* guide,
+                                               int W, int H, size_t guide_stride, int n, int r, float eps, float* out, void* ws, void* stream)
+{
+    return guided_upscale_batch<int16_t>(disp16, Wlo, Hlo, disp_stride, guide, W, H, guide_stride, n, r, eps, out, ws, stream);
 }

@@ -1170,11 +1170,23 @@ __device__ __forceinline__ void ccl_union(int* L, int a, int b)
 }
 __device__ __forceinline__ bool ccl_conn(int a, int b, int newVal, int maxDiff) { return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
 
-// one WAVE per image row (four rows per block), 64 pixels per step: "latest run start at or before x" is an inclusive
-// max-scan and "run starts before x" a ballot + popcount inside the wave, the carry from step to step rides in SGPRs --
-// no LDS, no barrier.  The left / right neighbours come from the lanes next door; the first pixel of the next step is
-// fetched one step ahead.  (The block-per-row form with 256-pixel chunks and two LDS exchanges per chunk: 0.18 ms per
-// 30 frames; this form ~40 % fewer wave-instructions.)
+// one WAVE per image row (four rows per block), 256 pixels per step -- FOUR consecutive pixels per lane (one 8-byte load,
+// one 16-byte label store): "latest run start at or before x" is a 3-step max inside the lane + an inclusive max-scan of
+// the lane totals over the wave (DPP row shifts + row broadcasts, no LDS), "run starts before x" four ballots + popcounts;
+// the carry from step to step rides in SGPRs, no barrier.  A 1920-pixel row is 8 steps.  (Round 2's one-pixel-per-lane
+// form ran 30 steps per row with six ds_bpermute exchanges each: 0.157 ms per 30 frames.)
+#define V3D_DPP_ROW_BCAST15 0x142
+#define V3D_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v)      // inclusive max-scan over the 64 lanes, identity 0
+{
+    v = max(v, dpp_mov<V3D_DPP_ROW_SHR(1)>(0u, v));
+    v = max(v, dpp_mov<V3D_DPP_ROW_SHR(2)>(0u, v));
+    v = max(v, dpp_mov<V3D_DPP_ROW_SHR(4)>(0u, v));
+    v = max(v, dpp_mov<V3D_DPP_ROW_SHR(8)>(0u, v));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, V3D_DPP_ROW_BCAST15, 0xA, 0xF, false));   // rows 1, 3 take lane 15 / 47
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, V3D_DPP_ROW_BCAST31, 0xC, 0xF, false));   // rows 2, 3 take lane 31
+    return v;
+}
 __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff,
                                                   int* __restrict__ lab, int* __restrict__ runs, int* __restrict__ csz)
 {
@@ -1182,48 +1194,65 @@ __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ im
     if (y >= H) return;                                        // wave-uniform
     const size_t fo = (size_t)blockIdx.z * W * H + (size_t)y * W;
     const int16_t* row = img + fo;
-    int carry = -1, nrun = 0;                                  // latest run start so far, runs so far (wave-uniform)
+    const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) & 7) | (reinterpret_cast<uintptr_t>(lab) & 15)) == 0;   // rows (and frames) start aligned: vector loads / stores
+    int carry = 0, nrun = 0;                                   // (latest run start so far) + 1, runs so far (wave-uniform)
     int last_v = newVal;                                       // value of the pixel left of this step's first one
-    // a step is ~50 instructions, a load ~1.5 us: the row's pixels are fetched RP steps ahead (static ring)
-    constexpr int RP = 4;
-    int vq[RP];
+    auto ld4 = [&](int x0, int (&v)[4]) {                      // pixels x0 .. x0+3 (newVal beyond the row)
+        if (vec) {
+            if (x0 < W) { const uint2 t = *reinterpret_cast<const uint2*>(row + x0);
+                          v[0] = (short)(t.x & 0xFFFFu); v[1] = (short)(t.x >> 16); v[2] = (short)(t.y & 0xFFFFu); v[3] = (short)(t.y >> 16); }
+            else { v[0] = v[1] = v[2] = v[3] = newVal; }
+        } else {
 #pragma unroll
-    for (int j = 0; j < RP; j++) vq[j] = (lane + 64 * j < W) ? (int)row[lane + 64 * j] : newVal;
-    for (int xq = 0; xq < W; xq += 64 * RP) {
-#pragma unroll
-      for (int j = 0; j < RP; j++) {
-        const int x0 = xq + 64 * j;
-        if (x0 < W) {                                          // uniform
-        const int x = x0 + lane;
-        const bool in = x < W;
-        const int v = vq[j];
-        vq[j] = (x + 64 * RP < W) ? (int)row[x + 64 * RP] : newVal;
-        const int vn0 = __builtin_amdgcn_readfirstlane(vq[(j + 1) % RP]);    // first pixel of the next step (read with all lanes active)
-        int pv = __shfl_up(v, 1), nv = __shfl_down(v, 1);
+            for (int k = 0; k < 4; k++) v[k] = x0 + k < W ? (int)row[x0 + k] : newVal;
+        }
+    };
+    int nx[4];
+    ld4(4 * lane, nx);
+    for (int xs = 0; xs < W; xs += 256) {
+        const int x0 = xs + 4 * lane;
+        int v[4] = { nx[0], nx[1], nx[2], nx[3] };
+        ld4(x0 + 256, nx);                                     // next step's pixels fly during this step
+        // neighbours across the lane boundary: left of v[0] = lane-1's v[3], right of v[3] = lane+1's v[0]
+        int pv = __shfl_up(v[3], 1), nv = __shfl_down(v[0], 1);
+        const int vn0 = __builtin_amdgcn_readfirstlane(nx[0]); // first pixel of the next step
         pv = lane == 0 ? last_v : pv;
         nv = lane == 63 ? vn0 : nv;
-        last_v = __builtin_amdgcn_readlane(v, 63);
-        const bool valid = in && v != newVal;
-        const bool start = valid && !ccl_conn(pv, v, newVal, maxDiff);
-        int m = start ? x : -1;
+        last_v = __builtin_amdgcn_readlane(v[3], 63);
+        bool valid[4], start[4];
+        uint32_t c[4];                                         // inclusive (latest start + 1) inside the lane
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {               // inclusive max-scan inside the wave
-            const int o = __shfl_up(m, off);
-            if (lane >= off) m = max(m, o);
+        for (int k = 0; k < 4; k++) {
+            valid[k] = x0 + k < W && v[k] != newVal;
+            start[k] = valid[k] && !ccl_conn(k ? v[k - 1] : pv, v[k], newVal, maxDiff);
+            const uint32_t m = start[k] ? (uint32_t)(x0 + k + 1) : 0u;
+            c[k] = k ? max(c[k - 1], m) : m;
         }
-        const int cur = max(m, carry);                         // run start of pixel x (if valid)
-        carry = max(carry, __builtin_amdgcn_readlane(m, 63));
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(start);
-        const int pos = nrun + __popcll(sm & ((1ull << lane) - 1ull));
-        nrun += __popcll(sm);
-        if (in) {
-            const size_t i = fo + x;
-            lab[i] = valid ? y * W + cur : -1;
-            if (start) runs[fo + pos] = y * W + x;
-            if (valid && !(x + 1 < W && ccl_conn(v, nv, newVal, maxDiff))) csz[fo + cur] = x - cur + 1;   // I am the run's last pixel: its length
+        const uint32_t incl = wave_incl_max_u32(c[3]);
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+        excl = max(lane == 0 ? 0u : excl, (uint32_t)carry);    // latest start + 1 left of this lane's pixels
+        carry = max(carry, (int)__builtin_amdgcn_readlane((int)incl, 63));
+        int before = nrun;                                     // run starts left of this lane's pixels
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long sm = __builtin_amdgcn_ballot_w64(start[k]);
+            before += __popcll(sm & ((1ull << lane) - 1ull));
+            nrun += __popcll(sm);
         }
+        int labv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cur = (int)max(c[k], excl) - 1;          // run start of pixel x0+k (if valid)
+            labv[k] = valid[k] ? y * W + cur : -1;
+            if (start[k]) { runs[fo + before] = y * W + x0 + k; before++; }
+            const int right = k < 3 ? v[k + 1] : nv;
+            if (valid[k] && !(x0 + k + 1 < W && ccl_conn(v[k], right, newVal, maxDiff))) csz[fo + cur] = x0 + k - cur + 1;   // the run's last pixel: its length
         }
-      }
+        if (vec) { if (x0 < W) *reinterpret_cast<int4*>(lab + fo + x0) = make_int4(labv[0], labv[1], labv[2], labv[3]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (x0 + k < W) lab[fo + x0 + k] = labv[k];
+        }
     }
     if (lane == 0 && nrun < W) runs[fo + nrun] = -1;           // end of the row's run list
 }
@@ -1231,22 +1260,41 @@ __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ im
 // Two launches: LEVEL 0 joins the row pairs inside bands of VM_BAND rows (trees at most VM_BAND deep), LEVEL 1 the
 // band boundaries.  The partition is the same in any order; what changes is the depth of the parent chains the
 // racing unions build, i.e. how many dependent global loads a find costs.
+// A thread tests EIGHT consecutive pixels of a row pair (two 16-byte loads + the pair left of them); one wave covers 512
+// columns.  (Round 2's one-pixel-per-thread form launched a million 30-instruction waves per batch: 0.21 ms per 30 frames,
+// bound by wave launch, not by its loads.)
 #define VM_BAND 16
 template <int LEVEL>
-__global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
+__global__ __launch_bounds__(64) void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8;
     const int y = LEVEL == 0 ? blockIdx.y + blockIdx.y / (VM_BAND - 1) : blockIdx.y * VM_BAND + VM_BAND - 1;
-    if (x >= W || y + 1 >= H) return;
+    if (x0 >= W || y + 1 >= H) return;
     const size_t fo = (size_t)blockIdx.z * W * H;
     const int16_t* im = img + fo; int* L = lab + fo;
-    const int i = y * W + x;
-    const int il = i - (x > 0 ? 1 : 0);                        // all four pixels are fetched together (one round trip, not two)
-    const int v = im[i], u = im[i + W], vl = im[il], ul = im[il + W];
-    if (!ccl_conn(v, u, newVal, maxDiff)) return;
-    // the pixel to my left joins the same two runs: it (or one further left) does the union
-    if (x > 0 && ccl_conn(vl, ul, newVal, maxDiff) && ccl_conn(vl, v, newVal, maxDiff) && ccl_conn(ul, u, newVal, maxDiff)) return;
-    ccl_union(L, L[i], L[i + W]);
+    const int i0 = y * W + x0;
+    int v[9], u[9];                                            // [0] = the pixel pair left of this thread's eight (itself at x0 = 0)
+    v[0] = im[i0 - (x0 > 0 ? 1 : 0)]; u[0] = im[i0 + W - (x0 > 0 ? 1 : 0)];
+    if ((W & 7) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {   // rows start 16-byte aligned
+        const uint4 a = *reinterpret_cast<const uint4*>(im + i0), b = *reinterpret_cast<const uint4*>(im + i0 + W);
+        const uint32_t aw[4] = { a.x, a.y, a.z, a.w }, bw[4] = { b.x, b.y, b.z, b.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[1 + 2 * k] = (short)(aw[k] & 0xFFFFu); v[2 + 2 * k] = (short)(aw[k] >> 16);
+            u[1 + 2 * k] = (short)(bw[k] & 0xFFFFu); u[2 + 2 * k] = (short)(bw[k] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int xc = min(x0 + k, W - 1) - x0; v[1 + k] = im[i0 + xc]; u[1 + k] = im[i0 + W + xc]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (x0 + k >= W) break;
+        if (!ccl_conn(v[1 + k], u[1 + k], newVal, maxDiff)) continue;
+        // the pixel to my left joins the same two runs: it (or one further left) does the union
+        if (x0 + k > 0 && ccl_conn(v[k], u[k], newVal, maxDiff) && ccl_conn(v[k], v[1 + k], newVal, maxDiff) && ccl_conn(u[k], u[1 + k], newVal, maxDiff)) continue;
+        ccl_union(L, L[i0 + k], L[i0 + k + W]);
+    }
 }
 
 // (3) and (4): one WAVE per image row walks that row's run list, 64 runs per step.
@@ -1309,8 +1357,8 @@ static int launch_speckles(int16_t* img, int W, int H, int frames, int newVal, i
     int* lab = ws; int* runs = ws + (size_t)px * frames; int* csz = ws + (size_t)px * frames * 2;
     hipLaunchKernelGGL(k_ccl_runs, dim3(v3d_cdiv(H, 4), 1, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab, runs, csz);
     // rows y with (y % VM_BAND) != VM_BAND-1 first (blockIdx.y enumerates them), then the band boundaries
-    hipLaunchKernelGGL(k_ccl_vmerge<0>, dim3(v3d_cdiv(W, 256), H - H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
-    if (H / VM_BAND > 0) hipLaunchKernelGGL(k_ccl_vmerge<1>, dim3(v3d_cdiv(W, 256), H / VM_BAND, frames), dim3(256), 0, st, img, W, H, newVal, maxDiff, lab);
+    hipLaunchKernelGGL(k_ccl_vmerge<0>, dim3(v3d_cdiv(W, 512), H - H / VM_BAND, frames), dim3(64), 0, st, img, W, H, newVal, maxDiff, lab);
+    if (H / VM_BAND > 0) hipLaunchKernelGGL(k_ccl_vmerge<1>, dim3(v3d_cdiv(W, 512), H / VM_BAND, frames), dim3(64), 0, st, img, W, H, newVal, maxDiff, lab);
     hipLaunchKernelGGL(k_ccl_count, dim3(v3d_cdiv(H, 4), 1, frames), dim3(256), 0, st, W, H, maxSize, lab, runs, csz);
     hipLaunchKernelGGL(k_ccl_apply, dim3(v3d_cdiv(H, 4), 1, frames), dim3(256), 0, st, img, W, H, newVal, maxSize, lab, runs, csz);
     V3D_LAUNCH_CHECK();

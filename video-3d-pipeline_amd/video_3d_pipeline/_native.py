@@ -21,7 +21,7 @@ EXPORTS = (
     "v3d_median3x3_i16", "v3d_filter_speckles", "v3d_sbs_to_gray", "v3d_split_sbs", "v3d_disp_to_depth",
     "v3d_depth_to_u16", "v3d_guided_upscale_ws_bytes", "v3d_guided_upscale", "v3d_bgr_to_gray",
     "v3d_corr_ws_bytes", "v3d_corr_lookup", "v3d_last_error", "v3d_version",
-    "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch",
+    "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch", "v3d_guided_upscale_disp16_batch",
     "v3d_sgbm_sync_errors", "v3d_sgbm_set_lockstep", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
     "v3d_mono_blend_ws_bytes", "v3d_mono_blend", "v3d_mono_blend_batch",
     "v3d_sgbm_poll_errors", "v3d_sgbm_stream_wait_lockstep", "v3d_sgbm_set_option", "v3d_sgbm_get_option", "v3d_set_option",
@@ -103,6 +103,7 @@ def lib():
         L.v3d_split_sbs.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
         L.v3d_sbs_to_gray_batch.argtypes = [vp, ci, ci, ci, ci, sz, ci, vp, vp, vp]
         L.v3d_guided_upscale_batch.argtypes = [vp, ci, ci, sz, vp, ci, ci, sz, ci, ci, C.c_float, vp, vp, vp]
+        L.v3d_guided_upscale_disp16_batch.argtypes = [vp, ci, ci, sz, vp, ci, ci, sz, ci, ci, C.c_float, vp, vp, vp]
         L.v3d_disp_to_depth.argtypes = [vp, sz, vp, vp]
         L.v3d_depth_to_u16.argtypes = [vp, sz, vp, vp, vp]
         L.v3d_guided_upscale_ws_bytes.argtypes = [ci, ci]
@@ -385,7 +386,9 @@ def guided_upscale(depth_lo, guide, r=8, eps=1e-3, out=None):
 
 
 def guided_upscale_batch(depth_lo, guide, r=8, eps=1e-3, out=None):
-    """depth_lo f32 [N,Hlo,Wlo] (contiguous), guide u8 [N,Hhi,Whi] (frames may be strided) -> f32 [N,Hhi,Whi], one launch pair"""
+    """depth_lo [N,Hlo,Wlo] (contiguous): float32 depth, or the matcher's int16 disparity x16 (then `/16` and `<= 0 -> 0`
+    of depth.py:341, 374 happen inside the filter's loads: same bits, no float plane); guide u8 [N,Hhi,Whi] (frames may be
+    strided) -> f32 [N,Hhi,Whi], one launch"""
     n, Hlo, Wlo = depth_lo.shape
     _, Hhi, Whi = guide.shape
     if guide.stride(2) != 1 or guide.stride(1) != Whi:
@@ -399,10 +402,12 @@ def guided_upscale_batch(depth_lo, guide, r=8, eps=1e-3, out=None):
         _gf_ws[key] = ws
     if guide.dtype != torch.uint8 or not guide.is_cuda:
         raise NativeError("guide: expected a uint8 device tensor")
-    _check(lib().v3d_guided_upscale_batch(_dev(depth_lo, torch.float32, "depth_lo"), Wlo, Hlo, Hlo * Wlo,
-                                          C.c_void_p(guide.data_ptr()), Whi, Hhi, guide.stride(0), n, int(r), float(eps),
-                                          _dev(out, torch.float32, "out"), _dev(ws, torch.uint8, "ws"), _stream()),
-           "v3d_guided_upscale_batch")
+    if depth_lo.dtype == torch.int16:
+        fn, name, src = lib().v3d_guided_upscale_disp16_batch, "v3d_guided_upscale_disp16_batch", _dev(depth_lo, torch.int16, "disp16")
+    else:
+        fn, name, src = lib().v3d_guided_upscale_batch, "v3d_guided_upscale_batch", _dev(depth_lo, torch.float32, "depth_lo")
+    _check(fn(src, Wlo, Hlo, Hlo * Wlo, C.c_void_p(guide.data_ptr()), Whi, Hhi, guide.stride(0), n, int(r), float(eps),
+              _dev(out, torch.float32, "out"), _dev(ws, torch.uint8, "ws"), _stream()), name)
     return out
 
 
