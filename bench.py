@@ -132,15 +132,113 @@ def bench_corr(args, N, dev):
     ms = e0.elapsed_time(e1) / steps
     alg = 2 * h * w * C * 2 + 2 * h * w * 4 + G * 9 * h * w * 4           # fl + fr bf16, flow, out f32 (~142 MB form A)
     flops = 2.0 * h * w * C * 9
+    # the kernels that ran, from the options in force (v3d_get_option), not from memory
+    if N.get_option("corr_gather"):
+        kernel = "k_corr_gather<0>"
+    elif N.get_option("corr_fused"):
+        kernel = "k_corr_fused0"
+    else:
+        kernel = "k_corr_warp + k_corr<0>"
+    # MFMA counters cannot be read in-process: taken from the newest committed rocprofv3 --pmc pass of this workload
+    # (tools/collect_profiles.sh -> profiles/rNN_corr_mfma.json), like `traffic` of the headline kernel
+    mfma, msrc = None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_corr_mfma.json")))
+    if files:
+        try:
+            mfma, msrc = json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+        except (OSError, ValueError):
+            mfma = None
+    # MFMA work actually issued: per 16-pixel tile and group two 16x16x32 MFMAs per 32 channels over 2 x 16 warped positions
+    # (32 x 16 x 64 MACs for 9 x 16 x 64 wanted ones); dense bf16 peak 2.5 PFLOP/s (MI355X_MICROARCH.md)
+    issued = 2.0 * 32 * 16 * 64 * G * ((w + 15) // 16) * h
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": alg / (ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "useful_gflops": flops / (ms * 1e-3) / 1e9, "issued_mfma_gflops": issued / (ms * 1e-3) / 1e9,
+            "issued_frac_of_bf16_peak": issued / (ms * 1e-3) / 2.5e15,
+            "mfma_util": (mfma or {}).get("mfma_util"), "mfma_counters": mfma, "mfma_source": msrc,
+            "note": "AI ~ 4 flop/B: HBM/L2 bound; MFMA only removes the VALU bottleneck"}
+    if mfma and kernel in (mfma.get("kernels") or {}):
+        roof["traffic"] = mfma["kernels"][kernel].get("traffic_bytes")
     return {"metric": "corr_lookups_per_s", "value": steps / el, "unit": "lookups/s", "n_gpus": 1,
             "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 in / f32 accumulate (MFMA 16x16x32)", "data": "synthetic",
             "config": {"workload": "configs[3]: correlation lookup 270x480x256, 4 groups x 9 offsets (1x9)"},
-            "roofline": {"bound": "hbm", "kernel": "k_corr_warp + k_corr<0>", "achieved": alg / (ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "useful_gflops": flops / (ms * 1e-3) / 1e9,
-                         "note": "AI ~ 4 flop/B: HBM/L2 bound; MFMA only removes the VALU bottleneck"},
-            "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": None}
+
+
+class _RawSinkPool:
+    """stands where utils.PngWriterPool stands: the 16-bit maps go to disk as raw little-endian samples (no zlib), so the rate
+    of the file-to-file path shows what the GPU side and the decode sustain next to the PNG-bound figure"""
+
+    def __init__(self):
+        self.count = 0
+
+    def submit(self, path, img_u16):
+        np.ascontiguousarray(img_u16).tofile(str(path) + ".raw")
+        self.count += 1
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def bench_cli(base_sbs, base_guide, n_depth=68, n_up=16):
+    """The PRODUCT path a caller of the reference gets (run_pipeline.py:63-98), file to file: synthetic .npy clip ->
+    HybridStereoDepthExtractor.process_video_sbs -> depth_%06d.png dir -> SimpleDepthUpscaler.process_depth_upscaling ->
+    4K 16-bit PNG sequence.  batch_size 8 is what run_pipeline.py:67 / depth.py:27 pass; the device pass is decoupled from
+    it (depth.py here: compute_batch_size).  The PNG figures are bound by zlib on the host cores; the raw-sink figures show
+    the same path without the compression."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from video_3d_pipeline.depth import HybridStereoDepthExtractor
+    from video_3d_pipeline.upscale import SimpleDepthUpscaler
+    work = tempfile.mkdtemp(prefix="v3d_cli_")
+    out = {"what": "synthetic 1080p SBS .npy clip -> process_video_sbs -> 16-bit PNG dir -> process_depth_upscaling (4K guide clip) -> 4K 16-bit PNGs",
+           "frames_depth": n_depth, "frames_upscale": n_up, "host_threads": len(os.sched_getaffinity(0))}
+    try:
+        nd = len(base_sbs)
+        clip = os.path.join(work, "sbs.npy")
+        np.save(clip, np.stack([base_sbs[i % nd] for i in range(n_depth)]))
+        clip4k = os.path.join(work, "v4k.npy")
+        np.save(clip4k, np.stack([np.repeat(base_guide[i % nd][..., None], 3, axis=2) for i in range(n_up)]))
+        sink = io.StringIO()
+        depth_dir = None
+        for label, bs, raw in (("batch8", 8, False), ("batch30", 30, False), ("batch8_raw_sink", 8, True)):
+            with contextlib.redirect_stdout(sink):
+                ex = HybridStereoDepthExtractor(work_dir=os.path.join(work, label), cache_dir=os.path.join(work, label), stereo_only=True, batch_size=bs)
+                if raw:
+                    ex.writer_pool_factory = _RawSinkPool
+                ex.process_video_sbs(clip, max_frames=min(n_depth, 34), force_reprocess=True)        # warm-up: workspace, first launches
+                t0 = time.perf_counter()
+                d = ex.process_video_sbs(clip, force_reprocess=True)
+                t1 = time.perf_counter()
+            out["depth_" + label] = {"value": n_depth / (t1 - t0), "unit": "frames/s", "batch_size": bs, "frames_per_device_pass": getattr(ex, "last_pass_frames", None)}
+            if not raw and depth_dir is None:
+                depth_dir = str(d)
+            ex.backend._matcher.close() if getattr(ex.backend, "_matcher", None) is not None else None
+            del ex
+        ddir = os.path.join(work, "d_up")
+        os.makedirs(ddir)
+        for i, f in enumerate(sorted(os.listdir(depth_dir))[:n_up]):
+            shutil.copy(os.path.join(depth_dir, f), os.path.join(ddir, f"depth_{i:06d}.png"))
+        for label, raw in (("upscale", False), ("upscale_raw_sink", True)):
+            with contextlib.redirect_stdout(sink):
+                up = SimpleDepthUpscaler()
+                if raw:
+                    up.writer_pool_factory = _RawSinkPool
+                up.process_depth_upscaling(ddir, clip4k, output_path=os.path.join(work, label + "_w.json"), force_reprocess=True)
+                t0 = time.perf_counter()
+                up.process_depth_upscaling(ddir, clip4k, output_path=os.path.join(work, label + ".json"), force_reprocess=True)
+                t1 = time.perf_counter()
+            out[label] = {"value": n_up / (t1 - t0), "unit": "frames/s"}
+        out["batch8_vs_batch30"] = out["depth_batch8"]["value"] / out["depth_batch30"]["value"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def latest_traffic():
@@ -186,7 +284,7 @@ class HotPath:
             self.gf_ev.append((e0, e1))
 
 
-def run_e2e(hp, h_sbs, h_gui, nb, steps, warmup):
+def run_e2e(hp, h_sbs, h_gui, nb, steps, warmup, ref0=None):
     """SURVEY 8(d) config (3) as specified: SBS frames + 4K guides start in PINNED HOST memory, the float32 4K depth ends in
     pinned host memory.  Three streams (H2D, compute, D2H), double-buffered device and host tensors: step s+1's inputs
     upload and step s-1's result downloads while step s computes.  Per-step events give a real per-batch latency
@@ -247,7 +345,12 @@ def run_e2e(hp, h_sbs, h_gui, nb, steps, warmup):
     gaps = [t_done[i].elapsed_time(t_done[i + 1]) for i in range(len(t_done) - 1)]
     mb = (h_sbs.numel() + h_gui.numel() + h_out[0].numel() * 4) / nb / 1e6
     fps = nb * steps / el
-    return {"value": fps, "unit": "frames/s", "frames_per_step": nb, "steps": steps,
+    # the leg's own output, stamped: frame 0 of the last step, as it arrived in pinned host memory, against the HBM-resident
+    # leg's frame 0 (same input frame, same kernels: the bits must agree; that frame is checked against the oracle)
+    stamp = None
+    if ref0 is not None:
+        stamp = bool(torch.equal(h_out[(steps - 1) & 1][0], ref0))
+    return {"value": fps, "unit": "frames/s", "frames_per_step": nb, "steps": steps, "output_equals_resident_leg": stamp,
             "latency_p50_ms_per_batch": statistics.median(lat), "latency_max_ms_per_batch": max(lat),
             "p50_ms_per_step": statistics.median(gaps) if gaps else el / steps * 1e3,
             "p50_ms_per_frame": (statistics.median(gaps) if gaps else el / steps * 1e3) / nb,
@@ -261,9 +364,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=30,
                     help="frames per step per GPU (the reference's --batch-size is 8; 30 = what one lock-step k_vdd launch holds co-resident)")
-    ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="auto",
-                    help="how rank 0 hands out the 4K guide rounds: broadcast the whole round (north_star), scatter each rank's "
-                         "frames (world x fewer bytes), or auto = broadcast if it hides behind one compute step, else scatter")
+    ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="scatter",
+                    help="how rank 0 hands out the 4K guide rounds: scatter each rank's own frames (default: 8.3 MB per frame and "
+                         "rank), broadcast whole rounds (north_star's variant: world x the bytes, 2 GB per 30-frame step at world 8), "
+                         "or auto = broadcast if one step's rounds hide behind a compute step, else scatter.  Whatever the choice, one "
+                         "round of `world` frames is timed both ways during warm-up and reported (config.guide_exchange_probe)")
     ap.add_argument("--workload", choices=["all", "full", "sgbm", "corr"], default="all",
                     help="all (default) = the headline line of `full` + `extra` {sgbm_only, corr, hh, batch8} at N = 1; full = BASELINE "
                          "configs[2] only; sgbm = configs[1] (disparity only) as the line; corr = configs[3] (bf16 MFMA correlation lookup)")
@@ -272,6 +377,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (then no parity_check either)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive pipeline leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the file-to-file product-path leg (extra.cli)")
+    ap.add_argument("--dump-frame0", default=None, metavar="NPZ",
+                    help="tests: rank 0 writes frame 0 of its last timed step (disp16 + 4K depth) to this .npz")
+    ap.add_argument("--test-inject-lockstep-timeout", action="store_true",
+                    help="tests only: make every lock-step workgroup of the first timed region report a time-out (drives the recovery path)")
     args = ap.parse_args()
 
     from video_3d_pipeline import _native as N, sharding, synthetic as syn
@@ -353,7 +463,12 @@ def main():
             return (rounds_src if rank == 0 else guide_buf[slot])[:, rank]
         return guide_buf[slot]
 
+    lockstep = {"raised": 0}
+
     def run(nsteps, timed):
+        """nsteps passes.  A lock-step time-out (V3D_ERR_LOCKSTEP: k_vdd_guard has raised the host flag, every later compute
+        on the handle is refused) must not unwind past the loop: the other ranks are still posting one collective per step,
+        so this rank keeps posting its own and only stops computing; the caller then switches ALL ranks together."""
         evs = []
         pending = exchange(0)
         for s in range(nsteps):
@@ -364,7 +479,11 @@ def main():
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 evs.append(e)
-            hp.step(sbs, my_guides(slot), upscale=full, timed=timed)
+            if not lockstep["raised"]:
+                try:
+                    hp.step(sbs, my_guides(slot), upscale=full, timed=timed)
+                except N.LockstepTimeout:
+                    lockstep["raised"] = 1
             pending = exchange(1 - slot) if s + 1 < nsteps else None          # after the step: its k_vdd event is the one to order behind
         if timed:
             e = torch.cuda.Event(enable_timing=True)
@@ -373,6 +492,22 @@ def main():
         return evs
 
     if side is not None:
+        # one round of `world` guide frames (north_star: "RCCL carrying only the 4K guide broadcast") timed as a broadcast and
+        # as a scatter, outside the timed region: the absolute cost of the collective on this node, whatever mode the steps use
+        one = torch.empty((world, Hh, Wh), dtype=torch.uint8, device=dev)
+        mine = torch.empty((Hh, Wh), dtype=torch.uint8, device=dev)
+        parts = [one[r] for r in range(world)] if rank == 0 else None
+        for name, fn in (("broadcast", lambda: dist.broadcast(one, src=0)), ("scatter", lambda: dist.scatter(mine, parts, src=0))):
+            fn(); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exch_info[name + "_one_round_ms"] = float(tt[0]) * 1e3
+        exch_info["round_bytes"] = {"broadcast": world * Hh * Wh, "scatter_per_rank": Hh * Wh}
+        del one, mine, parts
         if args.guide_exchange == "auto":
             # time one compute step and one full-round broadcast; keep the broadcast only if it hides behind the step
             mode["v"] = "broadcast"
@@ -384,7 +519,7 @@ def main():
             tt = torch.tensor([t_step, t_bc], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_step, t_bc = float(tt[0]), float(tt[1])
-            exch_info = {"step_ms": t_step * 1e3, "broadcast_ms": t_bc * 1e3}
+            exch_info.update({"step_ms": t_step * 1e3, "broadcast_step_rounds_ms": t_bc * 1e3})
             if t_bc > 0.5 * t_step:              # the exchange window is the part of a step behind k_vdd (about 60 % of it)
                 mode["v"] = "scatter"
                 guide_buf = None
@@ -408,10 +543,15 @@ def main():
         torch.cuda.synchronize()
         return evs, time.perf_counter() - t0
 
+    if args.test_inject_lockstep_timeout:
+        matcher.set_option("vdd_spin_limit", -1)          # test hook: every k_vdd workgroup reports a time-out
     evs, elapsed = timed_region()
     # a lock-step pass that timed out (GPU shared with another job) invalidated its outputs on the device: such a run is
     # not a measurement.  Do what depth.py does -- switch the handle to per-direction launches -- and time again.
-    timeouts = matcher.sync_errors()
+    timeouts = max(matcher.sync_errors(), lockstep["raised"])
+    lockstep["raised"] = 0
+    if args.test_inject_lockstep_timeout:
+        matcher.set_option("vdd_spin_limit", 0)
     recomputed = False
     if world > 1:
         t = torch.tensor([timeouts], dtype=torch.int64, device=dev)
@@ -501,6 +641,8 @@ def main():
         if recomputed:
             res["lockstep_timeouts_after_switch"] = matcher.sync_errors()
 
+        if args.dump_frame0:
+            np.savez(args.dump_frame0, disp=hp.disp[0].cpu().numpy(), q=hp.out4k[0].cpu().numpy() if full else np.zeros(0, np.float32))
         # ---- the timed region's own output against the oracle (frame 0 of the last step is base frame 0) ----
         if world == 1 and not args.no_cpu_baseline:
             cb, want_disp, want_q = cpu_baseline(base_sbs[0], base_guide[0])
@@ -527,13 +669,35 @@ def main():
             res["parity_check"] = None
 
         # ---- SURVEY 8(d) config (3) as specified: host in -> host out, pipelined ----
+        def guarded(fn):
+            """a leg behind the headline: a lock-step time-out (another tenant took CU slots) switches the handle to
+            per-direction launches and runs the leg again, and the leg says so -- never a traceback, never a silent number"""
+            try:
+                r = fn()
+                if hp.matcher.sync_errors() == 0:
+                    return r
+            except N.LockstepTimeout:
+                torch.cuda.synchronize()
+            hp.matcher.set_lockstep(False)
+            r = fn()
+            if isinstance(r, dict):
+                r["lockstep_recomputed"] = True
+            return r
+
         if full and world == 1 and not args.no_e2e:
             h_sbs_p, h_gui_p = h_sbs.pin_memory(), h_gui.pin_memory()
             e2e_steps = max(4, min(args.steps, 12))
+            ref0 = hp.out4k[0].cpu()                  # the resident leg's frame 0 (checked against the oracle above)
             e2e = {"what": "pinned host SBS + 4K guide -> H2D -> hot path -> D2H -> pinned host f32 4K depth; 3 streams, double-buffered",
-                   "batch%d" % B: run_e2e(hp, h_sbs_p, h_gui_p, B, e2e_steps, 2)}
+                   "batch%d" % B: guarded(lambda: run_e2e(hp, h_sbs_p, h_gui_p, B, e2e_steps, 2, ref0))}
             if B > 8:
-                e2e["batch8"] = run_e2e(hp, h_sbs_p, h_gui_p, 8, 2 * e2e_steps, 2)     # the reference's batch size (depth.py:27)
+                e2e["batch8"] = guarded(lambda: run_e2e(hp, h_sbs_p, h_gui_p, 8, 2 * e2e_steps, 2, ref0))     # the reference's batch size (depth.py:27)
+            e2e["output_equals_resident_leg"] = all(v.get("output_equals_resident_leg") is not False for v in e2e.values() if isinstance(v, dict))
+            if res.get("parity_check") is not None:
+                res["parity_check"]["e2e_output_equals_resident_leg"] = e2e["output_equals_resident_leg"]
+                res["parity_check"]["ok"] = bool(res["parity_check"]["ok"] and e2e["output_equals_resident_leg"])
+            if not e2e["output_equals_resident_leg"]:
+                rc = 3
             e2e["value"] = e2e["batch%d" % B]["value"]
             e2e["unit"] = "frames/s"
             e2e["p50_ms_per_frame"] = e2e["batch%d" % B]["p50_ms_per_frame"]
@@ -558,12 +722,12 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / nsteps
                 return {"value": n_frames / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames_per_step": n_frames, "steps": nsteps}
-            r = rate(lambda: hp.step(sbs, guide_own, upscale=False), B, st)
+            r = guarded(lambda: rate(lambda: hp.step(sbs, guide_own, upscale=False), B, st))
             r["config"] = "configs[1]: 1920x1080 SBS -> disparity (SBS split + SGBM + depth), no upscale"
             r["alg_frac_of_8TBps"] = sum(alg_bytes_per_frame()[0].values()) * B / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             extra["sgbm_only"] = r
             if B > 8:
-                r = rate(lambda: hp.step(sbs[:8], guide_own[:8]), 8, st)
+                r = guarded(lambda: rate(lambda: hp.step(sbs[:8], guide_own[:8]), 8, st))
                 r["config"] = "configs[2] at the reference's batch size 8 (depth.py:27), HBM-resident"
                 extra["batch8_hbm_resident"] = r
             extra["lockstep_timeouts"] = matcher.sync_errors()
@@ -572,12 +736,14 @@ def main():
             if args.sgbm_mode == "sgbm":
                 hh = N.StereoSGBM(W, H, B, device=dev, mode=1)
                 hp.matcher = hh
-                r = rate(lambda: hp.step(sbs, guide_own), B, st)
+                r = guarded(lambda: rate(lambda: hp.step(sbs, guide_own), B, st))
                 r["config"] = "configs[2] with MODE_HH (8 SGM paths)"
                 r["lockstep_timeouts"] = hh.sync_errors()
                 extra["hh"] = r
                 hh.close()
                 hp.matcher = None
+            if not args.no_cli:
+                extra["cli"] = bench_cli(base_sbs, base_guide)
             c = bench_corr(args, N, dev)
             extra["corr"] = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "config": c["config"]["workload"],
                              "roofline": c["roofline"], "dtype": c["dtype"]}

@@ -111,6 +111,7 @@ int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* value);
    kernel), "corr_fused" 1/0 (1x9 correlation as one gather-GEMM launch with the warped features staged in LDS / as a warp
    kernel + a GEMM kernel: same bits), "corr_gather" 0/1 (register-only gather-GEMM) */
 int v3d_set_option(const char* key, int value);
+int v3d_get_option(const char* key, int* value);
 
 /* per-stage HIP-event timing on the caller's stream (what bench.py's `roofline` object reads):
    v3d_sgbm_profile(h, 1) resets and enables; run compute calls; synchronise the stream;
@@ -148,6 +149,10 @@ int v3d_split_sbs(const uint8_t* sbs_bgr, int W, int H, int pitch, int unsqueeze
 int v3d_disp_to_depth(const int16_t* disp16, size_t n, float* depth_out, void* stream);
 /* minmax_ws: device scratch of >= 2 floats */
 int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, float* minmax_ws, void* stream);
+
+/* the upscaled depth as the 16-bit sample the PNG sink stores (stands where upscale.py:47-59 hands gray16 frames to the
+   encoder): out = clamp(rint(depth), 0, 65535), round-half-to-even */
+int v3d_round_to_u16(const float* depth, size_t n, uint16_t* out, void* stream);
 
 /* depth.py:344-374: depth_out[H][W] = clamp0(w_stereo * disp16/16 + w_mono * (resize(mono) - min) / (max - min) * 64), float32
    arithmetic in the reference's order (bit-identical to the NumPy expression); max == min leaves the stereo disparity.

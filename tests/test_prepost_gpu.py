@@ -86,3 +86,12 @@ def test_sbs_from_an_unaligned_base_pointer(native, oracle, off, unsqueeze):
     bl, br = native.split_sbs(view, unsqueeze)
     ol, orr = oracle.split_sbs(sbs, unsqueeze)
     assert np.array_equal(bl.cpu().numpy(), ol) and np.array_equal(br.cpu().numpy(), orr)
+
+
+def test_round_to_u16_is_rint_and_clamp(native):
+    """v3d_round_to_u16 (the 16-bit sample of the 4K PNG sink): numpy.rint + clip, halves to even, out-of-range and NaN"""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-50, 70000, 50000), np.arange(0, 300) + 0.5, [-0.5, 65534.5, 65535.5, 1e9, -1e9, np.nan]]).astype(np.float32)
+    want = np.clip(np.rint(np.nan_to_num(x, nan=0.0)), 0, 65535).astype(np.uint16)
+    got = native.round_to_u16(native.to_device(x)).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, want)

@@ -6,6 +6,7 @@
 #   TAG_pmc_fetch_size.csv / TAG_pmc_write_size.csv / traffic.json   separate --pmc FETCH_SIZE / WRITE_SIZE passes
 #   TAG_sq_full.txt                per-kernel SQ counter summary (two --pmc passes of 8 counters): VALU / LDS / wait cycles
 #   TAG_corr_kernel_stats.csv, TAG_corr_traffic.txt, TAG_corr_bench.json        the same for `--workload corr` (configs[3])
+#   TAG_corr_mfma.txt / .json      MFMA counters of the correlation kernels (SQ_VALU_MFMA_BUSY_CYCLES ... ) + mfma_util
 #   TAG_sgbm_kernel_stats.csv, TAG_sgbm_bench.json                               `--workload sgbm` (configs[1])
 # Every counter pass is its own rocprofv3 run with --pmc only (no trace domains), as the MI355X guide asks.
 TAG=${1:-r02_x}
@@ -34,6 +35,10 @@ cp $O/ktc/run_kernel_stats.csv $O/${TAG}_corr_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pfc -o run --output-format csv -- python3 bench.py --workload corr > $O/pfc.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/pwc -o run --output-format csv -- python3 bench.py --workload corr > $O/pwc.log 2>&1 || exit 1
 python3 tools/pmc_sq_summary.py $O/pfc/run_counter_collection.csv $O/pwc/run_counter_collection.csv > $O/${TAG}_corr_traffic.txt
+# MFMA utilisation of the correlation path (north_star: "rocprof HBM GB/s and MFMA utilisation"): its own --pmc pass
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/pmc_mfma -o run --output-format csv -- python3 bench.py --workload corr > $O/pmfma.log 2>&1 || exit 1
+python3 tools/corr_mfma.py $O/pmc_mfma/run_counter_collection.csv $O/pfc/run_counter_collection.csv $O/pwc/run_counter_collection.csv $O $TAG
+rm -rf $O/pmc_mfma
 echo "corr done"
 timeout -k 10 300 python3 bench.py --workload sgbm --no-cpu-baseline > $O/${TAG}_sgbm_bench.json 2>> $O/bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kts -o run --output-format csv -- python3 bench.py --steps 5 --no-cpu-baseline --workload sgbm > $O/kts.log 2>&1 || exit 1

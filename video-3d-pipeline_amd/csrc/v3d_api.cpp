@@ -34,3 +34,18 @@ extern "C" int v3d_set_option(const char* key, int value)
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
     return V3D_OK;
 }
+
+extern "C" int v3d_get_option(const char* key, int* value)
+{
+    if (!key || !value) { v3d_set_error("null argument"); return V3D_ERR_ARG; }
+    if (!strcmp(key, "gf_band1")) *value = g_v3d_opt.gf_band1;
+    else if (!strcmp(key, "gf_band2")) *value = g_v3d_opt.gf_band2;
+    else if (!strcmp(key, "gf_band")) *value = g_v3d_opt.gf_band;
+    else if (!strcmp(key, "gf_tiled")) *value = g_v3d_opt.gf_tiled;
+    else if (!strcmp(key, "gf_fused")) *value = g_v3d_opt.gf_fused;
+    else if (!strcmp(key, "gf_cols")) *value = g_v3d_opt.gf_cols;
+    else if (!strcmp(key, "corr_gather")) *value = g_v3d_opt.corr_gather;
+    else if (!strcmp(key, "corr_fused")) *value = g_v3d_opt.corr_fused;
+    else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
+    return V3D_OK;
+}

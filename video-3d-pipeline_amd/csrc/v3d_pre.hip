@@ -242,3 +242,21 @@ extern "C" int v3d_depth_to_u16(const float* depth, size_t n, uint16_t* out, flo
     V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
+
+// ---- 4K depth -> the 16-bit sample of the PNG sink: round to nearest even (numpy.rint / torch.round), clamp to [0, 65535] ----
+__global__ __launch_bounds__(256) void k_round_u16(const float* __restrict__ d, size_t n, uint16_t* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = rintf(d[i]);
+        out[i] = (uint16_t)(v >= 65535.f ? 65535.f : v > 0.f ? v : 0.f);        // NaN -> 0
+    }
+}
+extern "C" int v3d_round_to_u16(const float* depth, size_t n, uint16_t* out, void* stream)
+{
+    if (!depth || !out) { v3d_set_error("null pointer"); return V3D_ERR_ARG; }
+    if (n == 0) return V3D_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_round_u16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, n, out);
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}

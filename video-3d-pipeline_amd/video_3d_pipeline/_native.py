@@ -24,7 +24,7 @@ EXPORTS = (
     "v3d_sbs_to_gray_batch", "v3d_guided_upscale_batch", "v3d_guided_upscale_disp16_batch",
     "v3d_sgbm_sync_errors", "v3d_sgbm_set_lockstep", "v3d_sgbm_profile", "v3d_sgbm_profile_stage_count", "v3d_sgbm_profile_stage_name", "v3d_sgbm_profile_read",
     "v3d_mono_blend_ws_bytes", "v3d_mono_blend", "v3d_mono_blend_batch",
-    "v3d_sgbm_poll_errors", "v3d_sgbm_stream_wait_lockstep", "v3d_sgbm_set_option", "v3d_sgbm_get_option", "v3d_set_option",
+    "v3d_sgbm_poll_errors", "v3d_sgbm_stream_wait_lockstep", "v3d_sgbm_set_option", "v3d_sgbm_get_option", "v3d_set_option", "v3d_get_option", "v3d_round_to_u16",
 )
 
 ERR_LOCKSTEP = -4      # V3D_ERR_LOCKSTEP
@@ -87,6 +87,7 @@ def lib():
         L.v3d_sgbm_set_option.argtypes = [vp, C.c_char_p, ci]
         L.v3d_sgbm_get_option.argtypes = [vp, C.c_char_p, C.POINTER(ci)]
         L.v3d_set_option.argtypes = [C.c_char_p, ci]
+        L.v3d_get_option.argtypes = [C.c_char_p, C.POINTER(ci)]
         L.v3d_mono_blend_ws_bytes.argtypes = [ci]
         L.v3d_mono_blend_ws_bytes.restype = sz
         L.v3d_mono_blend.argtypes = [vp, ci, ci, vp, ci, ci, C.c_float, C.c_float, vp, vp, vp]
@@ -106,6 +107,7 @@ def lib():
         L.v3d_guided_upscale_disp16_batch.argtypes = [vp, ci, ci, sz, vp, ci, ci, sz, ci, ci, C.c_float, vp, vp, vp]
         L.v3d_disp_to_depth.argtypes = [vp, sz, vp, vp]
         L.v3d_depth_to_u16.argtypes = [vp, sz, vp, vp, vp]
+        L.v3d_round_to_u16.argtypes = [vp, sz, vp, vp]
         L.v3d_guided_upscale_ws_bytes.argtypes = [ci, ci]
         L.v3d_guided_upscale_ws_bytes.restype = sz
         L.v3d_guided_upscale.argtypes = [vp, ci, ci, vp, ci, ci, ci, C.c_float, vp, vp, vp]
@@ -126,6 +128,13 @@ def _check(rc, what):
 def set_option(key, value):
     """library-wide tuning switch (v3d_set_option): gf_band1, gf_band2, gf_tiled, gf_fused, corr_gather"""
     _check(lib().v3d_set_option(key.encode(), int(value)), f"v3d_set_option({key})")
+
+
+def get_option(key):
+    """current value of a library-wide switch (v3d_get_option)"""
+    v = C.c_int()
+    _check(lib().v3d_get_option(key.encode(), C.byref(v)), f"v3d_get_option({key})")
+    return v.value
 
 
 def _stream():
@@ -362,6 +371,14 @@ def depth_to_u16(depth):
     ws = torch.empty(2, dtype=torch.float32, device=depth.device)
     _check(lib().v3d_depth_to_u16(_dev(depth, torch.float32, "depth"), depth.numel(), _dev(out, torch.int16, "out"),
                                   _dev(ws, torch.float32, "ws"), _stream()), "v3d_depth_to_u16")
+    return out
+
+
+def round_to_u16(depth):
+    """float32 device tensor -> clamp(rint(x), 0, 65535) as uint16 bit patterns in an int16 tensor (torch has no uint16 math)"""
+    out = torch.empty(depth.shape, dtype=torch.int16, device=depth.device)
+    _check(lib().v3d_round_to_u16(_dev(depth, torch.float32, "depth"), depth.numel(), _dev(out, torch.int16, "out"), _stream()),
+           "v3d_round_to_u16")
     return out
 
 

@@ -196,6 +196,10 @@ class HipStereoBackend:
 class HybridStereoDepthExtractor:
     """ GPU-accelerated depth extraction from SBS video using hybrid stereo matching + neural guidance """
 
+    # where the 16-bit maps of process_video_sbs go: anything with PngWriterPool's submit(path, uint16 image) / context-
+    # manager surface (bench.py swaps in a raw sink to time the path without zlib)
+    writer_pool_factory = PngWriterPool
+
     def __init__(self,
                  model_checkpoint: str = "Intel/dpt-large",
                  work_dir: str = "temp_depth",
@@ -415,7 +419,7 @@ class HybridStereoDepthExtractor:
         provider = self._guidance_provider()
         # PNG compression (zlib) costs ~20 ms per 1080p map on one core, the GPU path 0.5 ms: the maps of a batch go to
         # a bounded pool of writer threads and compress while the next batch is decoded and computed
-        writers = PngWriterPool()
+        writers = self.writer_pool_factory()
 
         def flush():
             nonlocal processed_count

@@ -45,10 +45,9 @@ class HipUpscaleBackend:
 
     def upscale_u16(self, depth_lo, guide, r, eps) -> np.ndarray:
         """guided upscale, rounded and clamped to the 16-bit range of the PNG sink"""
-        torch = self.torch
         q = self.upscale(depth_lo, guide, r, eps)
-        # int32 -> int16 keeps the low 16 bits: the uint16 bit pattern leaves the device as 2 bytes per pixel
-        return torch.clamp(torch.round(q), 0, 65535).to(torch.int32).to(torch.int16).cpu().numpy().view(np.uint16)
+        # v3d_round_to_u16: the uint16 bit pattern leaves the device as 2 bytes per pixel
+        return self.native.round_to_u16(q.contiguous()).cpu().numpy().view(np.uint16)
 
     def flat_guide(self, h, w):
         return self.torch.full((h, w), 128, dtype=self.torch.uint8, device=self.device)
@@ -56,6 +55,8 @@ class HipUpscaleBackend:
 
 class SimpleDepthUpscaler:
     """ Depth upscaling to the 4K frame (guided filter on the GPU) """
+
+    writer_pool_factory = PngWriterPool       # sink of the 4K 16-bit maps (see HybridStereoDepthExtractor.writer_pool_factory)
 
     def __init__(self, use_nvenc: bool = True, radius: int = GUIDED_RADIUS, eps: float = GUIDED_EPS,
                  device: str = "cuda", backend=None):
@@ -148,7 +149,7 @@ class SimpleDepthUpscaler:
         # this rank's depth maps, decoded a few files ahead on reader threads (PNG inflate is the slowest host step)
         my_depth = prefetch_map(read_png16, [depth_files[i] for i in range(rank, n, world)])
         flat = 0
-        with PngWriterPool() as writers:                  # 4K 16-bit PNGs: ~80 ms of zlib each, compressed off the main thread
+        with self.writer_pool_factory() as writers:                  # 4K 16-bit PNGs: ~80 ms of zlib each, compressed off the main thread
             posted = post_round(0) if exchange is not None else False
             for base in range(0, n, world):
                 # one round ahead: the collective of round base+world runs on the exchange's side stream while this

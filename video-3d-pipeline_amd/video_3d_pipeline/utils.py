@@ -176,6 +176,11 @@ def iter_frames(video_path: str, start_frame: int = 0, max_frames: Optional[int]
         proc.wait()
 
 
+# writer / reader threads of the PNG pools; None = from the host cores (at most 16 writers / 8 readers).  A module
+# attribute, not an environment variable: the package reads none (tools set it directly)
+IO_THREADS = None
+
+
 def encode_png16(img_u16: np.ndarray, level: int = 1) -> bytes:
     """16-bit single-channel PNG as bytes (what cv2.imwrite produces for a uint16 array, depth.py:406).
     Written with zlib directly: filter type "sub" per row, deflate level 1.  zlib.compress releases the GIL, so a pool
@@ -215,12 +220,11 @@ class PngWriterPool:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         if workers is None:
-            env = os.environ.get("V3D_PNG_THREADS")
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 4
-            workers = int(env) if env else max(1, min(16, ncpu))
+            workers = IO_THREADS if IO_THREADS else max(1, min(16, ncpu))
         self.workers = max(1, workers)
         self._ex = ThreadPoolExecutor(self.workers, thread_name_prefix="v3d-png")
         self._slots = threading.Semaphore(max_pending if max_pending else 4 * self.workers)
@@ -330,12 +334,11 @@ def prefetch_map(fn, items, workers: int = None, lookahead: int = None):
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     if workers is None:
-        env = os.environ.get("V3D_PNG_THREADS")
         try:
             ncpu = len(os.sched_getaffinity(0))
         except AttributeError:
             ncpu = os.cpu_count() or 4
-        workers = int(env) if env else max(1, min(8, ncpu))
+        workers = IO_THREADS if IO_THREADS else max(1, min(8, ncpu))
     lookahead = lookahead or 2 * workers
     with ThreadPoolExecutor(workers, thread_name_prefix="v3d-read") as ex:
         q, it = deque(), iter(items)
