@@ -6,9 +6,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of `--batch` synthetic SBS frames (default 30 = what one
-co-resident lock-step k_vdd launch holds at 1080p; the reference's own batch_size is 8, depth.py:27 -- the same path at
-batch 8 is reported under `e2e.batch8` and `extra.batch8_hbm_resident`) already resident in HBM:
+One "step" = one pass of the hot path over one batch of `--batch` synthetic SBS frames (default: what ONE co-resident
+lock-step k_vdd launch holds at 1080p, 34 frames on 256 CUs; the reference's own batch_size is 8, depth.py:27 -- the same
+path at batch 8 is reported under `e2e.batch8` and `extra.batch8_hbm_resident`) already resident in HBM:
 v3d_sbs_to_gray -> v3d_sgbm_compute_batch -> v3d_guided_upscale_disp16_batch (depth.py:341/374's `/16` + clamp inside its loads)
 against the 4K guide -> float32 4K depth in HBM.  Frames shard round-robin over ranks (weak scaling: every rank runs a full batch per step); the only
 collective is the 4K guide round from rank 0 (RCCL), double-buffered on a side stream and ordered BEHIND the lock-step
@@ -207,7 +207,7 @@ def bench_cli(base_sbs, base_guide, n_depth=68, n_up=16):
         np.save(clip4k, np.stack([np.repeat(base_guide[i % nd][..., None], 3, axis=2) for i in range(n_up)]))
         sink = io.StringIO()
         depth_dir = None
-        for label, bs, raw in (("batch8", 8, False), ("batch30", 30, False), ("batch8_raw_sink", 8, True)):
+        for label, bs, raw in (("batch8", 8, False), ("batch34", 34, False), ("batch8_raw_sink", 8, True)):
             with contextlib.redirect_stdout(sink):
                 ex = HybridStereoDepthExtractor(work_dir=os.path.join(work, label), cache_dir=os.path.join(work, label), stereo_only=True, batch_size=bs)
                 if raw:
@@ -235,7 +235,7 @@ def bench_cli(base_sbs, base_guide, n_depth=68, n_up=16):
                 up.process_depth_upscaling(ddir, clip4k, output_path=os.path.join(work, label + ".json"), force_reprocess=True)
                 t1 = time.perf_counter()
             out[label] = {"value": n_up / (t1 - t0), "unit": "frames/s"}
-        out["batch8_vs_batch30"] = out["depth_batch8"]["value"] / out["depth_batch30"]["value"]
+        out["batch8_vs_batch34"] = out["depth_batch8"]["value"] / out["depth_batch34"]["value"]
     finally:
         shutil.rmtree(work, ignore_errors=True)
     return out
@@ -362,8 +362,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=30,
-                    help="frames per step per GPU (the reference's --batch-size is 8; 30 = what one lock-step k_vdd launch holds co-resident)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per step per GPU; 0 (default) = what ONE lock-step k_vdd launch holds co-resident at this width (the handle's "
+                         "vdd_frames_per_launch_dpl8: 34 at 1080p on 256 CUs).  The reference's --batch-size is 8 (list chunking, depth.py:448-461)")
     ap.add_argument("--guide-exchange", choices=["auto", "broadcast", "scatter", "none"], default="scatter",
                     help="how rank 0 hands out the 4K guide rounds: scatter each rank's own frames (default: 8.3 MB per frame and "
                          "rank), broadcast whole rounds (north_star's variant: world x the bytes, 2 GB per 30-frame step at world 8), "
@@ -403,6 +404,10 @@ def main():
     if world > 1:
         sharding.init_process_group(args.dist_backend)
     B = args.batch
+    if B <= 0:
+        probe = N.StereoSGBM(W, H, 1, device=dev)
+        B = max(1, probe.get_option("vdd_frames_per_launch_dpl8"))
+        probe.close()
     full = args.workload in ("all", "full")
 
     # ---- synthetic inputs: N_DISTINCT distinct frames per rank, cycled through the batch, resident in HBM ----

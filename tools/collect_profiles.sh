@@ -21,7 +21,8 @@ cp $O/kt/run_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
 echo "kernel stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o run --output-format csv -- python3 bench.py --steps 3 --no-cpu-baseline --no-e2e --workload full > $O/pf.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o run --output-format csv -- python3 bench.py --steps 3 --no-cpu-baseline --no-e2e --workload full > $O/pw.log 2>&1 || exit 1
-python3 tools/make_traffic.py $O/pf/run_counter_collection.csv $O/pw/run_counter_collection.csv $O $TAG
+FPL=$(python3 -c "import json,sys; print(json.load(open('$O/${TAG}_bench.json'))['config']['frames_per_step_per_gpu'])")
+python3 tools/make_traffic.py $O/pf/run_counter_collection.csv $O/pw/run_counter_collection.csv $O $TAG $FPL
 echo "traffic done"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
     -d $O/sq1 -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --workload full > $O/sq1.log 2>&1 || exit 1

@@ -30,6 +30,9 @@
 #ifndef V3D_X_COSTCHAIN
 #define V3D_X_COSTCHAIN 0       // timing proxy: one SGM chain step per row inside k_cost (VALU cost of hosting the left path there)
 #endif
+#ifndef V3D_X_P1L2
+#define V3D_X_P1L2 0            // timing proxy: k_hfused's phase 1 reads an L1- (1) / L2-resident (2) window (same loads, no HBM bytes; results garbage)
+#endif
 #define VOL_PX (V3D_RIL * V3D_D)                                   // elements between pixel x and x + 1 of a row
 __host__ __device__ static inline size_t vol_row(int y, int W1) { return ((size_t)(y / V3D_RIL) * W1 * V3D_RIL + (size_t)(y % V3D_RIL)) * V3D_D; }
 __host__ __device__ static inline size_t vol_frame(int H, int W1) { return (size_t)((H + V3D_RIL - 1) / V3D_RIL) * V3D_RIL * W1 * V3D_D; }
@@ -639,7 +642,11 @@ __device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nb
         // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
         Vec cb[K];
 #pragma unroll
+#if V3D_X_P1L2
+        for (int jj = 0; jj < K; jj++) cb[jj] = *reinterpret_cast<const Vec*>(Crow + (size_t)((xb + jj) & (V3D_X_P1L2 == 1 ? 63 : 1023)) * (VOL_PX * 2));
+#else
         for (int jj = 0; jj < K; jj++) cb[jj] = HfC<DPL>::load(Crow, xb + jj, dl);
+#endif
 #pragma unroll
         for (int jj = 0; jj < K; jj++) {
             uint32_t cv[NP], L[NP];
@@ -680,7 +687,12 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
     const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
 
+#if V3D_X_P1L2
+    // 1: every wave reads rows 0..3 of frame 0, 64 pixels (32 KB: L1-resident); 2: 16 rows x 1024 pixels (2 MB: L2-resident)
+    if (PH & 1) hf_phase1<DPL>(HfC<DPL>::base(a.C, 0, H, W1, (V3D_X_P1L2 == 1 ? 0 : (gw & 3) * 4) + sub, dl), ck, nblk, dl, P1pk, P2pk);
+#else
     if (PH & 1) hf_phase1<DPL>(Crow, ck, nblk, dl, P1pk, P2pk);
+#endif
 
     // ---------------- phase 2: right -> left, block by block ----------------
     unsigned char* myS = sS + wib * 64 * WTA_ROWB;
