@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_gf(const TD* __restrict__ depth_lo, int
 #ifndef GF_CH
 #define GF_CH 3      // 16-byte LDS reads in flight per plane in the horizontal phase
 #endif
+#ifndef GF_X_HPROXY
+#define GF_X_HPROXY 0   // timing proxy (results garbage): k_gff's horizontal window sums skip their middle chunks (a third of H1's, 60 % of H2's reads and adds)
+#endif
 typedef double v3d_f64x2 __attribute__((ext_vector_type(2)));
 typedef float v3d_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -387,6 +390,16 @@ __global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, in
 // Measured on 30 4K frames: 2.15 ms against 2.72 ms for the two sweeps (VALU pipe 61 % busy, LDS pipe 62 %: the kernel is
 // bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
 // skips the count reciprocals away from the border (more spills, 2.26 ms), s_setprio for the stage-1 waves (2.21-2.25 ms).
+// Round 3 (34 frames, same box, tools/gf_ab.py): a build whose horizontal phases skip a third of H1's and 60 % of H2's reads and
+// adds (GF_X_HPROXY) runs 65.7 us per frame against 75.1 -- so the window sums are worth ~15-20 %.  The form that saves them,
+// SLIDING RUNS (a lane owns 4 or 8 consecutive outputs of a row, first window summed once, then one add and one subtract per
+// output and plane; 22 or 30 adds for 4 or 8 outputs instead of 34 or 68), needs a quarter or an eighth of the lanes, so the
+// horizontal phase of a step was given to a rotating worker group of two waves (runs of 4) or one wave (runs of 8) while the
+// role's other waves went to the barrier: identical output, total instructions -15 %, and SLOWER -- 97.4 us per frame (runs of
+// 4) and 151.4 (runs of 8) against 75.7.  A step is one barrier-to-barrier interval; its length is the LATENCY of the longest
+// wave, and a worker that sums a window and then walks 8 dependent a/b solves (two reciprocal refinements each, ~25 dependent
+// f64 operations per output) is three times as long as a wave that does one pixel pair.  The pair form spreads exactly that
+// chain over all lanes; what remains is its instruction count.  (Kernel kept out of the tree; numbers in DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
 template <int RR, int COLS, typename TD>
 __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ depth_lo, int Wlo, int Hlo,
@@ -474,6 +487,7 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 double f = 0.0, l = 0.0, c = 0.0;
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += GF_CH) {
+                                    if (GF_X_HPROXY && ch > 0 && ch + GF_CH <= RR) continue;
                                     v3d_f64x2 w[GF_CH];
 #pragma unroll
                                     for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) w[i] = d[ch + i];
@@ -492,6 +506,7 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 const int4* gi = reinterpret_cast<const int4*>(&sVi[hb][hrow][0]) + (hq - RR / 2);
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += 3) {
+                                    if (GF_X_HPROXY && ch > 0 && ch + 3 <= RR) continue;
                                     int4 u[3];
 #pragma unroll
                                     for (int i = 0; i < 3; i++) if (ch + i <= RR) u[i] = gi[ch + i];
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 double f = 0.0, l = 0.0, c = 0.0;
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += 2) {
+                                    if (GF_X_HPROXY && ch > 0 && ch + 2 <= RR) continue;
                                     v3d_f64x2 w[2];
 #pragma unroll
                                     for (int i = 0; i < 2; i++) if (ch + i <= RR) w[i] = d[ch + i];
