@@ -14,6 +14,7 @@ out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
 variants = [v for v in os.environ.get("VARIANTS", "HFUSED=0,DPL=8;HFUSED=1,DPL=8;HFUSED=1,DPL=4;HFUSED=0,DPL=4").split(";")]
 ref = None
 ms = {}
+stage_min = {}
 for rnd in range(int(os.environ.get("ROUNDS", "2"))):
     for v in variants:
         env = dict(os.environ)
@@ -30,7 +31,8 @@ for rnd in range(int(os.environ.get("ROUNDS", "2"))):
         if ref is None: ref = chk
         tot = sum(st.values()) / calls
         ms.setdefault(v, []).append(tot)
+        for k, x in st.items(): stage_min.setdefault(v, {})[k] = min(stage_min.get(v, {}).get(k, 1e9), x / calls)
         if rnd == 0:
             print(f"{v:22s} total {tot:7.3f} ms/batch  " + " ".join(f"{k.replace('chain_', '')}={x / calls:.3f}" for k, x in st.items() if x / calls > 0.01) + ("  OK" if chk == ref else "  MISMATCH") + f" chk={chk}")
         m.close()
-for v in variants: print(f"{v:22s} min {min(ms[v]):.3f} ms/batch -> {min(ms[v]) / B:.3f} ms/frame")
+for v in variants: print(f"{v:22s} min {min(ms[v]):.3f} ms/batch -> {min(ms[v]) / B:.3f} ms/frame   stage minima: " + " ".join(f"{k.replace('chain_', '')}={x:.3f}" for k, x in stage_min[v].items() if x > 0.01))

@@ -353,6 +353,8 @@ struct ChainArgs {
     int uniq;                 // uniquenessRatio
     uint32_t* wta;            // MODE 2: [nframes][H][W] WTA records (wta_word); columns < 64 are never written
     int xcd;                  // k_hfused: XCD-contiguous row-group order (V3D_HF_XCD=1).  Measured 4 % slower: off
+    int persist;              // k_hfused: 0 = one wave per row group; 1 = the resident number of waves draws row groups from `ticket`
+    int* ticket;
 };
 
 // minimum of both halves of `mn` over the LPP lanes of a pixel, returned in BOTH halves.  One v_pk_min_u16 with op_sel
@@ -663,7 +665,7 @@ __device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nb
 
 // PH: 3 = both phases in one launch; 2 = phase 2 only (k_hscan has dropped the checkpoints before)
 template <int DPL, int PH>
-__global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restrict__ ckpt)
+__global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __restrict__ ckpt)      // four waves per SIMD: the 128-VGPR budget
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, K = 64 / PPW;
     typedef typename VecT<DPL>::type Vec;
@@ -671,31 +673,41 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
 
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int W1 = a.W1, H = a.H;
-    const int groups = (H + PPW - 1) / PPW;
-    const int gw = (a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x) * 4 + wib;
-    const int frame = gw / groups, grp = gw - frame * groups;
-    if (frame >= a.nframes) return;                            // wave-uniform; no block-wide barriers below
-
+    const int groups = (H + PPW - 1) / PPW, total = groups * a.nframes;
     const int sub = lane / LPP, dl = lane % LPP;
+    const int nblk = (W1 + K - 1) / K;
+    const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
+    const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
+    unsigned char* myS = sS + wib * 64 * WTA_ROWB;
+    // Ticketed form (a.persist): exactly the resident number of waves is launched and each draws (frame, row group) tickets
+    // until none is left, instead of one wave per row group: no partly filled last "round" of the 4096 wave slots (34 frames
+    // are 2.24 rounds).  Measured per 34 / 68 frames: 4.76 -> 4.56 ms / 9.46 -> 8.98 ms; 30 frames (1.98 rounds): unchanged.
+    // (Also measured, round 3: letting the odd waves run their left-to-right scan one group AHEAD, so that both phases are on
+    //  the chip at all times instead of all waves streaming, then all waves computing -- 4-7 % SLOWER at every batch size: the
+    //  kernel does not suffer from its waves marching in step.)
+    auto draw = [&]() -> int {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(a.ticket, 1);
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    int work = a.persist ? draw() : (a.xcd ? (int)xcd_linear(blockIdx.x, gridDim.x) : (int)blockIdx.x) * 4 + wib;
+    for (;;) {
+    if (work >= total) break;                                  // wave-uniform; no block-wide barriers anywhere
+    {
+    const int frame = work / groups, grp = work - frame * groups;
     const int c0 = grp * PPW, c1 = min(c0 + PPW, H) - 1;
     const int cc = min(c0 + sub, c1);
     const char* Crow = HfC<DPL>::base(a.C, frame, H, W1, cc, dl);
     const int16_t* Srow = a.S + (size_t)frame * vol_frame(H, W1) + vol_row(cc, W1) + dl * DPL;
-    const int nblk = (W1 + K - 1) / K;
     uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;         // [blk][reg][lane]; delta is recomputed
-
-    const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
-    const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
-
 #if V3D_X_P1L2
     // 1: every wave reads rows 0..3 of frame 0, 64 pixels (32 KB: L1-resident); 2: 16 rows x 1024 pixels (2 MB: L2-resident)
-    if (PH & 1) hf_phase1<DPL>(HfC<DPL>::base(a.C, 0, H, W1, (V3D_X_P1L2 == 1 ? 0 : (gw & 3) * 4) + sub, dl), ck, nblk, dl, P1pk, P2pk);
+    if (PH & 1) hf_phase1<DPL>(HfC<DPL>::base(a.C, 0, H, W1, (V3D_X_P1L2 == 1 ? 0 : (work & 3) * 4) + sub, dl), ck, nblk, dl, P1pk, P2pk);
 #else
     if (PH & 1) hf_phase1<DPL>(Crow, ck, nblk, dl, P1pk, P2pk);
 #endif
 
     // ---------------- phase 2: right -> left, block by block ----------------
-    unsigned char* myS = sS + wib * 64 * WTA_ROWB;
     uint32_t q[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) q[i] = 0;
@@ -755,6 +767,10 @@ __global__ __launch_bounds__(256) void k_hfused(ChainArgs a, uint32_t* __restric
             const int x = x0 + K - 1 - wj, y = c0 + wsub;
             wta_pixel(myS + lane * WTA_ROWB, (y <= c1) && (x < W1), x, y, frame, a);
         }
+    }
+    }
+    if (!a.persist) break;
+    work = draw();
     }
 }
 
@@ -1397,6 +1413,8 @@ struct v3d_sgbm {
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
     int cost_band;                              // rows per k_cost workgroup
     int vdd_xcd, cost_xcd, hf_xcd;
+    int hf_persist;                             // k_hfused: 0 one wave per row group, 1 resident waves draw row groups from a ticket counter
+    int* hf_ticket;
     int vdd_mf4, vdd_mf8;                       // frames per launch of each mapping at maxW (reported by get_option)
     int vdd_occ4, vdd_occ8, ncu;                // occupancy query results the bounds are derived from
     int reserve_cus;                            // CUs left to other streams' kernels (e.g. an RCCL collective) when sizing a lock-step launch
@@ -1465,6 +1483,7 @@ static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_
 //   "cost_band"      >= 8 rows per k_cost workgroup
 //   "cost_xcd", "vdd_xcd", "hf_xcd"   1/0  XCD-contiguous workgroup order of that kernel
 //   "hsplit"         1/0  k_hfused's left-to-right scan as its own launch (measured: no gain; kept for A/B)
+//   "hf_persist"     1/0  k_hfused as the resident number of waves drawing row groups from a ticket counter / one wave per row group
 //   "reserve_cus"    CUs other streams keep busy while a lock-step pass runs (shrinks the frames per launch)
 //   "vdd_launch_frames"  frames per lock-step launch (0 = from the occupancy query); larger than the chip holds is safe, slow
 //   "vdd_spin_limit" poll rounds a lane may wait in a lock-step pass (0 = 64 per row + 4096; -1 = test hook: every
@@ -1483,6 +1502,7 @@ extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
     else if (is("cost_xcd")) { if (value != 0 && value != 1) return bad(); h->cost_xcd = value; }
     else if (is("vdd_xcd")) { if (value != 0 && value != 1) return bad(); h->vdd_xcd = value; }
     else if (is("hf_xcd")) { if (value != 0 && value != 1) return bad(); h->hf_xcd = value; }
+    else if (is("hf_persist")) { if (value != 0 && value != 1) return bad(); h->hf_persist = value; }
     else if (is("reserve_cus")) { if (value < 0 || value > h->ncu) return bad(); h->reserve_cus = value; vdd_size_launches(h); }
     else if (is("vdd_spin_limit")) { if (value < -1) return bad(); h->vdd_spin_limit = value; }
     else if (is("vdd_launch_frames")) { if (value < 0) return bad(); h->vdd_launch_frames = value; }
@@ -1502,6 +1522,7 @@ extern "C" int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* valu
     else if (is("cost_xcd")) *value = h->cost_xcd;
     else if (is("vdd_xcd")) *value = h->vdd_xcd;
     else if (is("hf_xcd")) *value = h->hf_xcd;
+    else if (is("hf_persist")) *value = h->hf_persist;
     else if (is("reserve_cus")) *value = h->reserve_cus;
     else if (is("vdd_spin_limit")) *value = h->vdd_spin_limit;
     else if (is("vdd_launch_frames")) *value = h->vdd_launch_frames;
@@ -1559,6 +1580,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         const size_t ng = (size_t)maxB * nstrips_max * 2 * VDD_RING * VDD_GRAN;
         rc |= ws_alloc(&h->gran, ng, &h->bytes); h->gran_bytes = ng * sizeof(unsigned long long);
         rc |= ws_alloc(&h->vdd_err, 64, &h->bytes);
+        h->hf_ticket = h->vdd_err ? h->vdd_err + 32 : nullptr;       // k_hfused's ticket counter shares the small allocation
         if (!rc) { (void)hipMemset(h->gran, 0, ng * sizeof(unsigned long long)); (void)hipMemset(h->vdd_err, 0, 64 * sizeof(int)); }
         h->err_host = nullptr;
         if (!rc && hipHostMalloc((void**)&h->err_host, 64, hipHostMallocDefault) != hipSuccess) { h->err_host = nullptr; rc = 1; }
@@ -1576,6 +1598,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         h->vdd_occ4 = b4 > 2 ? 2 : b4; h->vdd_occ8 = b8 > 2 ? 2 : b8; h->ncu = ncu;
         vdd_size_launches(h);
     }
+    h->hf_persist = 1;                                   // measured: -4 % at 34 / 68 frames, neutral at 30
     h->vdd_xcd = 0; h->hf_xcd = 0; h->cost_xcd = 1;      // measured: XCD-contiguous order pays for k_cost only
     h->cost_band = 90;
     if (rc) { v3d_sgbm_destroy(h); return V3D_ERR_HIP; }
@@ -1684,7 +1707,7 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
 
     ChainArgs a;
     a.C = h->C; a.S = h->S; a.W1 = W1; a.H = H; a.W = W; a.nframes = n; a.P1 = h->P1; a.P2 = h->P2; a.uniq = h->uniq;
-    a.wta = h->wta; a.xcd = h->hf_xcd;
+    a.wta = h->wta; a.xcd = h->hf_xcd; a.persist = 0; a.ticket = h->hf_ticket;
     // direction order is free (sums commute; saturation of non-negative addends is order-independent)
     const bool use_vdd = vdd_usable(h) && H < 4095;
     if (use_vdd) {
@@ -1726,8 +1749,17 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
             if (h->dpl == 4) { hipLaunchKernelGGL(k_hscan<4>, g4, dim3(256), 0, st, a, h->ckpt); hipLaunchKernelGGL((k_hfused<4, 2>), g4, dim3(256), 0, st, a, h->ckpt); }
             else { hipLaunchKernelGGL(k_hscan<8>, g8, dim3(256), 0, st, a, h->ckpt); hipLaunchKernelGGL((k_hfused<8, 2>), g8, dim3(256), 0, st, a, h->ckpt); }
         } else {
-            if (h->dpl == 4) hipLaunchKernelGGL((k_hfused<4, 3>), g4, dim3(256), 0, st, a, h->ckpt);
-            else hipLaunchKernelGGL((k_hfused<8, 3>), g8, dim3(256), 0, st, a, h->ckpt);
+            dim3 l4 = g4, l8 = g8;
+            if (h->hf_persist) {                            // resident waves only: 4 workgroups of 4 waves per CU (LDS / 119 VGPRs)
+                a.persist = h->hf_persist;
+                V3D_HIP_CHECK(hipMemsetAsync(h->hf_ticket, 0, sizeof(int), st));
+                const unsigned res = (unsigned)h->ncu * 4u;
+                if (l4.x > res) l4.x = res;
+                if (l8.x > res) l8.x = res;
+            }
+            if (h->dpl == 4) hipLaunchKernelGGL((k_hfused<4, 3>), l4, dim3(256), 0, st, a, h->ckpt);
+            else hipLaunchKernelGGL((k_hfused<8, 3>), l8, dim3(256), 0, st, a, h->ckpt);
+            a.persist = 0;
         }
     } else
         launch_chain<true, -1, false, 2>(h, a, st);     // r4: (x+1, y), + WTA tail
