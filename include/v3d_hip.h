@@ -98,7 +98,7 @@ int v3d_sgbm_set_lockstep(v3d_sgbm* h, int enable);
 int v3d_sgbm_stream_wait_lockstep(v3d_sgbm* h, void* stream);
 
 /* Tuning switches of a handle (defaults = the measured best; results never change): "lockstep" 0/1, "hfused" 0/1,
-   "chain_dpl" 4/8, "hsplit" 0/1, "hf_persist" 0/1, "vdd_dpl" 0/4/8, "cost_band" >= 8, "cost_xcd" / "vdd_xcd" / "hf_xcd" 0/1, "reserve_cus" (CUs
+   "chain_dpl" 4/8, "hsplit" 0/1, "hf_persist" 0/1, "lrm_tiles" 0/1, "vdd_dpl" 0/4/8, "cost_band" >= 8, "cost_xcd" / "vdd_xcd" / "hf_xcd" 0/1, "reserve_cus" (CUs
    other streams keep busy during a lock-step pass), "vdd_spin_limit" (poll rounds per lane; 0 = derived from the row
    count), "vdd_launch_frames" (frames per lock-step launch; 0 = sized from the occupancy query and the call's width).
    get also knows the read-only "vdd_frames_per_launch_dpl4" / "_dpl8".  Unknown key or bad value: V3D_ERR_ARG.

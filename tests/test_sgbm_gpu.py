@@ -224,7 +224,8 @@ def test_parameter_sweep(native, oracle, kw, vdd):
     W, H = 250, 64
     L, R = textured_pair(W, H, seed=sum(kw.values()) + 3)
     want = oracle.sgbm_compute(L, R, oracle.default_params(**kw))
-    m = native.StereoSGBM(max_width=W, max_height=H, options={"lockstep": vdd, "hfused": vdd}, **kw)
+    # vdd = 0 also takes the round-2 forms of the small kernels: L-R check + median as tiles, k_hfused one wave per row group
+    m = native.StereoSGBM(max_width=W, max_height=H, options={"lockstep": vdd, "hfused": vdd, "lrm_tiles": 1 - vdd, "hf_persist": vdd}, **kw)
     got = m.compute(_dev(native, L), _dev(native, R)).cpu().numpy()
     assert m.sync_errors() == 0
     m.close()
@@ -426,3 +427,21 @@ def test_speckle_run_lists_extremes(native, oracle, W, H):
             want = oracle.filter_speckles(img, -16, max_size, max_diff)
             assert not mismatch_report(got, want, f"{name} {W}x{H} size<={max_size} diff<={max_diff}"), \
                 mismatch_report(got, want, f"{name} {W}x{H} size<={max_size} diff<={max_diff}")
+
+
+@pytest.mark.parametrize("W,H", [(70, 5), (257, 33), (300, 31), (1920, 64), (2500, 40), (4000, 12)])
+def test_lrcheck_median_row_march_equals_tiles_and_oracle(native, oracle, W, H):
+    """the L-R check + 3x3 median as a row march over full-width bands (default; 8 or 16 pixels per thread and row) against
+    the 128 x 16 tile form and the oracle: band edges (30-row bands), image borders, widths that end mid-thread-stride, the raw
+    (no median) export too"""
+    import torch
+    L, R = textured_pair(W, H, seed=W + H)
+    want = oracle.sgbm_compute(L, R)
+    outs = {}
+    for tiles in (0, 1):
+        m = native.StereoSGBM(max_width=W, max_height=H, options={"lrm_tiles": tiles})
+        outs[tiles] = (m.compute(_dev(native, L), _dev(native, R)), m.debug_raw(_dev(native, L), _dev(native, R)))
+        assert m.sync_errors() == 0
+        m.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not mismatch_report(outs[0][0].cpu().numpy(), want, f"{W}x{H}")

@@ -3,7 +3,7 @@ C-ABI (v3d_sgbm_set_option / v3d_set_option).  The library itself reads no envir
 import os
 
 _SGBM = {"V3D_VDD": "lockstep", "V3D_HFUSED": "hfused", "V3D_HSPLIT": "hsplit", "V3D_CHAIN_DPL": "chain_dpl", "V3D_VDD_DPL": "vdd_dpl",
-         "V3D_COST_BAND": "cost_band", "V3D_COST_XCD": "cost_xcd", "V3D_VDD_XCD": "vdd_xcd", "V3D_HF_XCD": "hf_xcd", "V3D_HF_PERSIST": "hf_persist",
+         "V3D_COST_BAND": "cost_band", "V3D_COST_XCD": "cost_xcd", "V3D_VDD_XCD": "vdd_xcd", "V3D_HF_XCD": "hf_xcd", "V3D_HF_PERSIST": "hf_persist", "V3D_LRM_TILES": "lrm_tiles",
          "V3D_RESERVE_CUS": "reserve_cus", "V3D_VDD_SPIN_LIMIT": "vdd_spin_limit"}
 _LIB = {"V3D_GF_BAND1": "gf_band1", "V3D_GF_BAND2": "gf_band2", "V3D_GF_TILED": "gf_tiled", "V3D_GF_FUSED": "gf_fused",
         "V3D_CORR_GATHER": "corr_gather"}

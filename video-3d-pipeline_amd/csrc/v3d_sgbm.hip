@@ -1150,6 +1150,136 @@ __global__ __launch_bounds__(256) void k_lrcheck_median(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same three steps as a ROW MARCH (round 3; the default for even W <= 4096).  The tile form above stages 256 source columns x 18
+// rows for 128 x 16 outputs: every record is fetched 2.25 times, and a block's 36 KB of LDS leave few blocks per CU.  Here
+// a 256-thread block owns a band of rows at the full image width and marches down it: per row each thread loads its own
+// records (coalesced, every record read once per band + 2 halo rows per band), the right-view keys are min-scattered into ONE
+// LDS row, the checked disparities go into a three-row LDS ring and the median of the previous row comes out of it.  10 bytes
+// of LDS per column (19 KB at 1920), the next row's records fly while the current row is processed.  Same minimum over the
+// same key set, same median network (run on two adjacent outputs at once in packed int16): bit-identical to the tile form.
+// ------------------------------------------------------------------------------------------------
+#define LRR_BAND 15
+#define V3D_SORT2PK(a, b) { const uint32_t _lo = pk_min(a, b), _hi = pk_max(a, b); a = _lo; b = _hi; }
+template <bool MED, int NPP>      // NPP: pixel PAIRS per thread and row (columns 2t, 2t+1, 2t + 512, ...): 4 covers W <= 2048, 8 W <= 4096; W even
+__global__ __launch_bounds__(256) void k_lrcheck_median_rows(const uint32_t* __restrict__ wta, int W, int H, int d12, int16_t* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lrr_smem[];
+    uint32_t* sD2 = reinterpret_cast<uint32_t*>(lrr_smem);                    // [W] right-view keys of the current row
+    uint32_t* sT = reinterpret_cast<uint32_t*>(lrr_smem + (size_t)W * 4);     // [3][W/2] checked disparities, two per word: ring of rows
+    const int t = threadIdx.x, f = blockIdx.z, W2 = W >> 1;
+    const int ya = blockIdx.x * LRR_BAND, yb = min(ya + LRR_BAND, H);
+    const size_t fo = (size_t)f * H * W;
+    auto load_row = [&](int y, uint2 (&r)[NPP]) {                              // records of image row clamp(y); columns < 64 were never written
+        const uint2* src = reinterpret_cast<const uint2*>(wta + fo + (size_t)min(max(y, 0), H - 1) * W);
+#pragma unroll
+        for (int i = 0; i < NPP; i++) r[i] = src[min(t + 256 * i, W2 - 1)];
+    };
+    uint2 nx[NPP];
+    const int y_first = MED ? ya - 1 : ya, y_last = MED ? yb : yb - 1;
+    load_row(y_first, nx);
+    // rows ya-1 .. yb (median needs a row above and below; replicated at the image border = the clamped load)
+    for (int y = y_first; y <= y_last; y++) {
+        uint32_t rec[2 * NPP];
+#pragma unroll
+        for (int i = 0; i < NPP; i++) {
+            const int x = 2 * (t + 256 * i);
+            rec[2 * i] = (x >= V3D_D && x < W) ? nx[i].x : 0u; rec[2 * i + 1] = (x >= V3D_D && x < W) ? nx[i].y : 0u;
+        }
+        load_row(y + 1, nx);                                                   // the next row's records fly during this row (clamped: always in range)
+        for (int x = t; x < W; x += 256) sD2[x] = 0xFFFFFFFFu;
+        __syncthreads();
+        // ---- right-view keys: the d of the cheapest source pixel of every target column (ties: larger d), by LDS min-scatter ----
+#pragma unroll
+        for (int i = 0; i < 2 * NPP; i++) {
+            const uint32_t v = rec[i];
+            const int best = (int)(v & 63u);
+            if ((v & 0x1FFC0u) != 0u) atomicMin(&sD2[2 * (t + 256 * (i >> 1)) + (i & 1) - best], ((v >> 17) << 6) | (uint32_t)(63 - best));
+        }
+        __syncthreads();
+        // ---- L-R check (stereosgbm.cpp: both roundings of the disparity must disagree) ----
+        uint32_t* row = sT + (size_t)((y + 3) % 3) * W2;
+#pragma unroll
+        for (int i = 0; i < NPP; i++) {
+            const int x0 = 2 * (t + 256 * i);
+            if (x0 < W) {
+                int dd[2];
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const int x = x0 + n;
+                    int d1 = V3D_INVALID16;
+                    if (x >= V3D_D) {
+                        d1 = wta_d16(rec[2 * i + n]);
+                        if (d1 != V3D_INVALID16) {
+                            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+                            const uint32_t ka = sD2[x - da], kb = sD2[x - db];
+                            const bool bad = (ka != 0xFFFFFFFFu) && (abs(63 - (int)(ka & 63u) - da) > d12) &&
+                                             (kb != 0xFFFFFFFFu) && (abs(63 - (int)(kb & 63u) - db) > d12);
+                            if (bad) d1 = V3D_INVALID16;
+                        }
+                    }
+                    dd[n] = d1;
+                }
+                const uint32_t w = ((uint32_t)dd[0] & 0xFFFFu) | ((uint32_t)dd[1] << 16);
+                if (MED) row[x0 >> 1] = w; else *reinterpret_cast<uint32_t*>(out + fo + (size_t)y * W + x0) = w;
+            }
+        }
+        __syncthreads();
+        if (!MED) continue;
+        // ---- 3x3 median of row y-1 from ring rows y-2, y-1, y: two adjacent outputs per 19-exchange network in packed int16 ----
+        const int yo = y - 1;
+        if (yo >= ya && yo < yb) {                                             // uniform
+            // at the image border the missing row is the replicated one: row -1 was loaded as row 0, row H as row H-1
+            const uint32_t* rr[3] = { sT + (size_t)((yo - 1 + 3) % 3) * W2, sT + (size_t)((yo + 3) % 3) * W2, sT + (size_t)((yo + 1 + 3) % 3) * W2 };
+#pragma unroll
+            for (int i = 0; i < NPP; i++) {
+                const int xw = t + 256 * i;                                    // word index: outputs 2 xw, 2 xw + 1
+                if (xw < W2) {
+                    uint32_t p[9];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const uint32_t w0 = rr[r][xw];
+                        const uint32_t wl = xw > 0 ? rr[r][xw - 1] : (w0 << 16);              // column -1 replicates column 0
+                        const uint32_t wr = xw + 1 < W2 ? rr[r][xw + 1] : (w0 >> 16);         // column W replicates column W-1
+                        p[3 * r] = alignbit(w0, wl, 16); p[3 * r + 1] = w0; p[3 * r + 2] = alignbit(wr, w0, 16);   // (x-1, x), (x, x+1), (x+1, x+2)
+                    }
+                    V3D_SORT2PK(p[1], p[2]); V3D_SORT2PK(p[4], p[5]); V3D_SORT2PK(p[7], p[8]); V3D_SORT2PK(p[0], p[1]);
+                    V3D_SORT2PK(p[3], p[4]); V3D_SORT2PK(p[6], p[7]); V3D_SORT2PK(p[1], p[2]); V3D_SORT2PK(p[4], p[5]);
+                    V3D_SORT2PK(p[7], p[8]); V3D_SORT2PK(p[0], p[3]); V3D_SORT2PK(p[5], p[8]); V3D_SORT2PK(p[4], p[7]);
+                    V3D_SORT2PK(p[3], p[6]); V3D_SORT2PK(p[1], p[4]); V3D_SORT2PK(p[2], p[5]); V3D_SORT2PK(p[4], p[7]);
+                    V3D_SORT2PK(p[4], p[2]); V3D_SORT2PK(p[6], p[4]); V3D_SORT2PK(p[4], p[2]);
+                    *reinterpret_cast<uint32_t*>(out + fo + (size_t)yo * W + 2 * xw) = p[4];
+                }
+            }
+        }
+        // (no barrier here: the next trip first refills sD2 -- its last readers finished before the barrier above -- and overwrites
+        //  ring row (y+1) % 3, the row this median read as its first, only behind its own two barriers)
+    }
+}
+
+static int launch_lrcheck_median(const uint32_t* wta, int W, int H, int n, int d12, int16_t* out, bool med, int tiles, hipStream_t st)
+{
+    // the row march reads record pairs and writes disparity pairs: even widths, 8-byte aligned buffers
+    const bool rows_ok = !tiles && W <= 4096 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(wta) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+    if (rows_ok) {
+        const dim3 grid(v3d_cdiv(H, LRR_BAND), 1, n);
+        const size_t smem = (size_t)W * 4 + (size_t)3 * (W / 2) * 4;
+        if (W <= 2048) {
+            if (med) hipLaunchKernelGGL((k_lrcheck_median_rows<true, 4>), grid, dim3(256), smem, st, wta, W, H, d12, out);
+            else hipLaunchKernelGGL((k_lrcheck_median_rows<false, 4>), grid, dim3(256), smem, st, wta, W, H, d12, out);
+        } else {
+            if (med) hipLaunchKernelGGL((k_lrcheck_median_rows<true, 8>), grid, dim3(256), smem, st, wta, W, H, d12, out);
+            else hipLaunchKernelGGL((k_lrcheck_median_rows<false, 8>), grid, dim3(256), smem, st, wta, W, H, d12, out);
+        }
+    } else {
+        const dim3 grid(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n);
+        if (med) hipLaunchKernelGGL(k_lrcheck_median<true>, grid, dim3(256), 0, st, wta, W, H, d12, out);
+        else hipLaunchKernelGGL(k_lrcheck_median<false>, grid, dim3(256), 0, st, wta, W, H, d12, out);
+    }
+    V3D_LAUNCH_CHECK();
+    return V3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a-8: filterSpeckles as run-based connected-component labelling.  Components are the 4-connected
 // sets of valid pixels joined where |a - b| <= maxDiff; components of at most maxSpeckleSize pixels
 // are invalidated.  (1) every row is cut into horizontal runs by a block-wide scan (no atomics);
@@ -1413,6 +1543,7 @@ struct v3d_sgbm {
     int vdd_dpl;                                // forced k_vdd mapping (4 / 8), 0 = choose per call
     int cost_band;                              // rows per k_cost workgroup
     int vdd_xcd, cost_xcd, hf_xcd;
+    int lrm_tiles;                              // 1: L-R check + median as 128 x 16 tiles (the round-2 form) instead of the row march
     int hf_persist;                             // k_hfused: 0 one wave per row group, 1 resident waves draw row groups from a ticket counter
     int* hf_ticket;
     int vdd_mf4, vdd_mf8;                       // frames per launch of each mapping at maxW (reported by get_option)
@@ -1483,6 +1614,7 @@ static inline bool vdd_usable(const v3d_sgbm* h) { return h->vdd_mode && h->vdd_
 //   "cost_band"      >= 8 rows per k_cost workgroup
 //   "cost_xcd", "vdd_xcd", "hf_xcd"   1/0  XCD-contiguous workgroup order of that kernel
 //   "hsplit"         1/0  k_hfused's left-to-right scan as its own launch (measured: no gain; kept for A/B)
+//   "lrm_tiles"      0/1  L-R check + median as a row march over full-width bands / as 128 x 16 tiles (round-2 form; also the form for W > 4096)
 //   "hf_persist"     1/0  k_hfused as the resident number of waves drawing row groups from a ticket counter / one wave per row group
 //   "reserve_cus"    CUs other streams keep busy while a lock-step pass runs (shrinks the frames per launch)
 //   "vdd_launch_frames"  frames per lock-step launch (0 = from the occupancy query); larger than the chip holds is safe, slow
@@ -1503,6 +1635,7 @@ extern "C" int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value)
     else if (is("vdd_xcd")) { if (value != 0 && value != 1) return bad(); h->vdd_xcd = value; }
     else if (is("hf_xcd")) { if (value != 0 && value != 1) return bad(); h->hf_xcd = value; }
     else if (is("hf_persist")) { if (value != 0 && value != 1) return bad(); h->hf_persist = value; }
+    else if (is("lrm_tiles")) { if (value != 0 && value != 1) return bad(); h->lrm_tiles = value; }
     else if (is("reserve_cus")) { if (value < 0 || value > h->ncu) return bad(); h->reserve_cus = value; vdd_size_launches(h); }
     else if (is("vdd_spin_limit")) { if (value < -1) return bad(); h->vdd_spin_limit = value; }
     else if (is("vdd_launch_frames")) { if (value < 0) return bad(); h->vdd_launch_frames = value; }
@@ -1523,6 +1656,7 @@ extern "C" int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* valu
     else if (is("vdd_xcd")) *value = h->vdd_xcd;
     else if (is("hf_xcd")) *value = h->hf_xcd;
     else if (is("hf_persist")) *value = h->hf_persist;
+    else if (is("lrm_tiles")) *value = h->lrm_tiles;
     else if (is("reserve_cus")) *value = h->reserve_cus;
     else if (is("vdd_spin_limit")) *value = h->vdd_spin_limit;
     else if (is("vdd_launch_frames")) *value = h->vdd_launch_frames;
@@ -1598,6 +1732,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
         h->vdd_occ4 = b4 > 2 ? 2 : b4; h->vdd_occ8 = b8 > 2 ? 2 : b8; h->ncu = ncu;
         vdd_size_launches(h);
     }
+    h->lrm_tiles = 0;
     h->hf_persist = 1;                                   // measured: -4 % at 34 / 68 frames, neutral at 30
     h->vdd_xcd = 0; h->hf_xcd = 0; h->cost_xcd = 1;      // measured: XCD-contiguous order pays for k_cost only
     h->cost_band = 90;
@@ -1766,14 +1901,14 @@ static int run_sgbm(v3d_sgbm* h, const uint8_t* left, const uint8_t* right, int 
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_LRCHECK, st);
     if (last_stage == 2) {
-        hipLaunchKernelGGL(k_lrcheck_median<false>, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->wta, W, H, h->d12, out);
+        if ((rc = launch_lrcheck_median(h->wta, W, H, n, h->d12, out, false, h->lrm_tiles, st)) != V3D_OK) return rc;
         if (use_vdd) hipLaunchKernelGGL(k_vdd_guard, dim3(256), dim3(256), 0, st, h->vdd_err, h->err_host, out, (size_t)px * n);
         V3D_LAUNCH_CHECK();
         prof_mark(h, ST_MEDIAN, st);
         return V3D_OK;
     }
     prof_mark(h, ST_MEDIAN, st);
-    hipLaunchKernelGGL(k_lrcheck_median<true>, dim3(v3d_cdiv(W, LRM_TX), v3d_cdiv(H, LRM_TY), n), dim3(256), 0, st, h->wta, W, H, h->d12, out);
+    if ((rc = launch_lrcheck_median(h->wta, W, H, n, h->d12, out, true, h->lrm_tiles, st)) != V3D_OK) return rc;
     V3D_LAUNCH_CHECK();
     prof_mark(h, ST_SPECKLE, st);
     if (h->prm.speckleWindowSize > 0) {
