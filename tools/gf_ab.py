@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "video-3d-pipeli
 import numpy as np, torch
 from video_3d_pipeline import _native as N, synthetic as syn
 import envopts; envopts.select_variant_lib(N); envopts.apply_lib_options(N)
+if os.environ.get('GF_BAND'): N.set_option('gf_band', int(os.environ['GF_BAND']))
 W, H, B = 1920, 1080, int(os.environ.get("QB_BATCH", "34"))
 disp = N.to_device(np.stack([(syn.gt_disparity(W, H) * 16).astype(np.int16)] * B)); guide = N.to_device(np.stack([syn.guide_frame(W, H, 0)] * B))
 out = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device="cuda")

@@ -21,7 +21,7 @@ extern "C" int v3d_set_option(const char* key, int value)
 {
     if (!key) { v3d_set_error("null key"); return V3D_ERR_ARG; }
     if (!strcmp(key, "gf_band1") || !strcmp(key, "gf_band2") || !strcmp(key, "gf_band")) {
-        if (value < 8 || value > 65536) { v3d_set_error("option %s: value %d out of range", key, value); return V3D_ERR_ARG; }
+        if ((value < 8 && !(value == 0 && key[7] == '\0')) || value > 65536) { v3d_set_error("option %s: value %d out of range", key, value); return V3D_ERR_ARG; }
         (key[7] == '1' ? g_v3d_opt.gf_band1 : key[7] == '2' ? g_v3d_opt.gf_band2 : g_v3d_opt.gf_band) = value;
     } else if (!strcmp(key, "gf_tiled")) g_v3d_opt.gf_tiled = value != 0;
     else if (!strcmp(key, "gf_fused")) g_v3d_opt.gf_fused = value != 0;

@@ -169,9 +169,6 @@ __global__ __launch_bounds__(256) void k_gf(const TD* __restrict__ depth_lo, int
 #ifndef GF_CH
 #define GF_CH 3      // 16-byte LDS reads in flight per plane in the horizontal phase
 #endif
-#ifndef GF_X_HPROXY
-#define GF_X_HPROXY 0   // timing proxy (results garbage): k_gff's horizontal window sums skip their middle chunks (a third of H1's, 60 % of H2's reads and adds)
-#endif
 typedef double v3d_f64x2 __attribute__((ext_vector_type(2)));
 typedef float v3d_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, in
 // bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
 // skips the count reciprocals away from the border (more spills, 2.26 ms), s_setprio for the stage-1 waves (2.21-2.25 ms).
 // Round 3 (34 frames, same box, tools/gf_ab.py): a build whose horizontal phases skip a third of H1's and 60 % of H2's reads and
-// adds (GF_X_HPROXY) runs 65.7 us per frame against 75.1 -- so the window sums are worth ~15-20 %.  The form that saves them,
+// adds (a proxy build, results garbage) runs 65.7 us per frame against 75.1 -- so the window sums are worth ~15-20 %.  The form that saves them,
 // SLIDING RUNS (a lane owns 4 or 8 consecutive outputs of a row, first window summed once, then one add and one subtract per
 // output and plane; 22 or 30 adds for 4 or 8 outputs instead of 34 or 68), needs a quarter or an eighth of the lanes, so the
 // horizontal phase of a step was given to a rotating worker group of two waves (runs of 4) or one wave (runs of 8) while the
@@ -487,7 +484,6 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 double f = 0.0, l = 0.0, c = 0.0;
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += GF_CH) {
-                                    if (GF_X_HPROXY && ch > 0 && ch + GF_CH <= RR) continue;
                                     v3d_f64x2 w[GF_CH];
 #pragma unroll
                                     for (int i = 0; i < GF_CH; i++) if (ch + i <= RR) w[i] = d[ch + i];
@@ -506,7 +502,6 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 const int4* gi = reinterpret_cast<const int4*>(&sVi[hb][hrow][0]) + (hq - RR / 2);
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += 3) {
-                                    if (GF_X_HPROXY && ch > 0 && ch + 3 <= RR) continue;
                                     int4 u[3];
 #pragma unroll
                                     for (int i = 0; i < 3; i++) if (ch + i <= RR) u[i] = gi[ch + i];
@@ -610,7 +605,6 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 double f = 0.0, l = 0.0, c = 0.0;
 #pragma unroll
                                 for (int ch = 0; ch <= RR; ch += 2) {
-                                    if (GF_X_HPROXY && ch > 0 && ch + 2 <= RR) continue;
                                     v3d_f64x2 w[2];
 #pragma unroll
                                     for (int i = 0; i < 2; i++) if (ch + i <= RR) w[i] = d[ch + i];
@@ -669,7 +663,23 @@ template <int RR, typename TD>
 static void launch_gff(const TD* depth_lo, int Wlo, int Hlo, const uint8_t* guide, int W, int H, double eps,
                        float* out, int n, size_t depth_stride, size_t guide_stride, hipStream_t st)
 {
-    const int band = g_v3d_opt.gf_band;
+    const int cols = g_v3d_opt.gf_cols == 512 ? 512 : 256;
+    int band = g_v3d_opt.gf_band;
+    if (band <= 0) {
+        // auto: every band pays 4r warm-up rows and the launch runs in whole "rounds" of the resident workgroups (equal-length
+        // workgroups: two per CU at 256 columns, one at 512), so pick the band count that minimises rounds x (band + 4r) --
+        // e.g. 34 4K frames on 256 CUs: 8 bands of 270 rows are 9.56 rounds = 10 x 302 row steps, 5 bands of 432 are 5.98 = 6 x 464
+        int dev = 0, ncu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const long slots = (long)ncu * (cols == 512 ? 1 : 2), strips = v3d_cdiv(W, cols - 4 * RR);
+        long best = -1;
+        for (int nb = 1; nb <= 64 && nb <= H; nb++) {
+            const int b = (v3d_cdiv(H, nb) + 1) & ~1;
+            const long wgs = strips * v3d_cdiv(H, b) * n, rounds = (wgs + slots - 1) / slots, cost = rounds * (b + 4 * RR);
+            if (best < 0 || cost < best) { best = cost; band = b; }
+        }
+    }
     if (g_v3d_opt.gf_cols == 512) {        // 512-column strips, 16 waves, one workgroup per CU: half the strip-halo recompute
         const dim3 grid(v3d_cdiv(W, 512 - 4 * RR), v3d_cdiv(H, band), n);
         hipLaunchKernelGGL((k_gff<RR, 512, TD>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);

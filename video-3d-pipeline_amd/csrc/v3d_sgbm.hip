@@ -24,15 +24,9 @@
 #ifndef V3D_X_SPLIT
 #define V3D_X_SPLIT 0           // 1: k_hfused's phase 1 (left->right scan, checkpoints) as its own launch k_hscan
 #endif
-#ifndef V3D_X_C12
-#define V3D_X_C12 0             // timing proxies of a 12-bit C: 1 k_hfused loads, 2 k_vdd<8> loads, 4 k_cost stores (results garbage)
-#endif
-#ifndef V3D_X_COSTCHAIN
-#define V3D_X_COSTCHAIN 0       // timing proxy: one SGM chain step per row inside k_cost (VALU cost of hosting the left path there)
-#endif
-#ifndef V3D_X_P1L2
-#define V3D_X_P1L2 0            // timing proxy: k_hfused's phase 1 reads an L1- (1) / L2-resident (2) window (same loads, no HBM bytes; results garbage)
-#endif
+// (Round 3's timing proxies -- a 12-bit C in each of the three big kernels, an SGM chain step hosted in k_cost, k_hfused's
+//  phase 1 reading an L1- / L2-resident window -- lived here as V3D_X_C12 / V3D_X_COSTCHAIN / V3D_X_P1L2 builds; their numbers
+//  are in DESIGN.md and profiles/r03_experiments/, the code in the history (commit "bench: default batch = one lock-step launch").)
 #define VOL_PX (V3D_RIL * V3D_D)                                   // elements between pixel x and x + 1 of a row
 __host__ __device__ static inline size_t vol_row(int y, int W1) { return ((size_t)(y / V3D_RIL) * W1 * V3D_RIL + (size_t)(y % V3D_RIL)) * V3D_D; }
 __host__ __device__ static inline size_t vol_frame(int H, int W1) { return (size_t)((H + V3D_RIL - 1) / V3D_RIL) * V3D_RIL * W1 * V3D_D; }
@@ -254,11 +248,6 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
         for (int i = 0; i < 5; i++) ring[i][j] = 0u; }
     // C store offsets: per-thread part (out-of-range marker for halo columns) + uniform row part
     const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * VOL_PX + EP * dq) * 2u : V3D_BUF_OOB;
-#if V3D_X_COSTCHAIN
-    uint32_t xp[NP], xdelta = pk_bcast(P2);
-#pragma unroll
-    for (int j = 0; j < NP; j++) xp[j] = 0u;
-#endif
 
     for (int k10 = 0; k10 < nrows; k10 += 10) {
 #pragma unroll
@@ -308,28 +297,6 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
 #pragma unroll
             for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
             const uint32_t st_row = k >= 4 ? (uint32_t)(vol_row(ys + k - 4, W1) * 2u) : V3D_BUF_OOB;     // uniform
-#if V3D_X_COSTCHAIN
-            {   // timing proxy: the left-path recurrence hosted here (one chain step per row on the fresh C vector, a checkpoint
-                // every 16 rows into the tail of the row's own C line -- results garbage)
-                uint32_t Lx[NP];
-                xdelta = chain_step<NP, LPC>(xp, xdelta, vs, Lx, pk_bcast(600), pk_bcast(P2), dq == 0, dq == LPC - 1);
-#pragma unroll
-                for (int j = 0; j < NP; j++) xp[j] = Lx[j];
-                if ((k & 15) == 15) buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(xp));
-            }
-#endif
-#if V3D_X_C12 & 4
-            if (NP == 4) {   // timing proxy of a 12-bit C: pack 8 x 12 bits into three dwords, one 12-byte store per lane
-                uint32_t t[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) t[j] = (vs[j] & 0xFFFu) | ((vs[j] >> 4) & 0xFFF000u);
-                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                const u32x3 pk = { t[0] | (t[1] << 24), (t[1] >> 8) | (t[2] << 16), (t[2] >> 16) | (t[3] << 8) };
-                const uint32_t c12 = out_col ? (uint32_t)((xr0 - 2 + col) * 96 + 12 * dq) : V3D_BUF_OOB;
-                const uint32_t r12 = k >= 4 ? (uint32_t)((ys + k - 4) * W1) * 96u : V3D_BUF_OOB;
-                __builtin_amdgcn_raw_buffer_store_b96(pk, rs_c, __builtin_elementwise_add_sat(c12, r12), 0, V3D_NT ? 2 : 0);
-            } else
-#endif
             buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(vs));   // saturating: marker + marker stays out of range
         }
       }
@@ -599,31 +566,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
 // run L_right backwards over it, form S + L_left + L_right on chip and do the WTA tail.
 // Cost: L_left is computed twice (+1 path of VALU), C is read twice, S once, never written.
 // ------------------------------------------------------------------------------------------------
-// 12-bit C timing proxy (V3D_X_C12 & 1): a lane's 4 disparities are 6 bytes at byte offset 6 * dl of a 96-byte pixel
-typedef uint32_t v3d_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-typedef uint32_t v3d_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
-__device__ __forceinline__ uint32_t unpack12_pair(uint32_t t) { return (t & 0xFFFu) | ((t << 4) & 0x0FFF0000u); }
 template <int DPL> struct HfC {
     typedef typename VecT<DPL>::type Vec;
     // pointer to the lane's disparities of pixel (row, x = 0) and the load of pixel x
     static __device__ __forceinline__ const char* base(const int16_t* C, int frame, int H, int W1, int row, int dl)
     {
-#if V3D_X_C12 & 1
-        if (DPL == 4) return reinterpret_cast<const char*>(C) + ((size_t)frame * H + row) * W1 * 96 + ((6 * dl) & ~3);
-#endif
         return reinterpret_cast<const char*>(C + (size_t)frame * vol_frame(H, W1) + vol_row(row, W1) + dl * DPL);
     }
     static __device__ __forceinline__ Vec load(const char* b, int x, int dl)
     {
-#if V3D_X_C12 & 1
-        if (DPL == 4) {
-            const v3d_u32x2_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x2_a4*>(b + (size_t)x * 96));
-            const uint32_t sh = (dl & 1) * 16;
-            const uint32_t lo = alignbit(v.y, v.x, sh), hi = v.y >> sh;
-            Vec r; r.x = unpack12_pair(lo); r.y = unpack12_pair(alignbit(hi, lo, 24));
-            return r;
-        }
-#endif
         return ld_stream(reinterpret_cast<const Vec*>(b + (size_t)x * (VOL_PX * 2)));
     }
 };
@@ -644,11 +595,7 @@ __device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nb
         // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
         Vec cb[K];
 #pragma unroll
-#if V3D_X_P1L2
-        for (int jj = 0; jj < K; jj++) cb[jj] = *reinterpret_cast<const Vec*>(Crow + (size_t)((xb + jj) & (V3D_X_P1L2 == 1 ? 63 : 1023)) * (VOL_PX * 2));
-#else
         for (int jj = 0; jj < K; jj++) cb[jj] = HfC<DPL>::load(Crow, xb + jj, dl);
-#endif
 #pragma unroll
         for (int jj = 0; jj < K; jj++) {
             uint32_t cv[NP], L[NP];
@@ -700,12 +647,7 @@ __global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __rest
     const char* Crow = HfC<DPL>::base(a.C, frame, H, W1, cc, dl);
     const int16_t* Srow = a.S + (size_t)frame * vol_frame(H, W1) + vol_row(cc, W1) + dl * DPL;
     uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;         // [blk][reg][lane]; delta is recomputed
-#if V3D_X_P1L2
-    // 1: every wave reads rows 0..3 of frame 0, 64 pixels (32 KB: L1-resident); 2: 16 rows x 1024 pixels (2 MB: L2-resident)
-    if (PH & 1) hf_phase1<DPL>(HfC<DPL>::base(a.C, 0, H, W1, (V3D_X_P1L2 == 1 ? 0 : (work & 3) * 4) + sub, dl), ck, nblk, dl, P1pk, P2pk);
-#else
     if (PH & 1) hf_phase1<DPL>(Crow, ck, nblk, dl, P1pk, P2pk);
-#endif
 
     // ---------------- phase 2: right -> left, block by block ----------------
     uint32_t q[NP];
@@ -918,19 +860,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
 
     Vec cq[PF];
     auto rowof = [&](int y) -> size_t { const int yc = min(y, H - 1); return vol_row(YREV ? H - 1 - yc : yc, W1); };
-#if V3D_X_C12 & 2
-    // timing proxy of a 12-bit C: a lane's 8 disparities are 12 bytes of a 96-byte pixel (results garbage)
-    const char* Cp12 = reinterpret_cast<const char*>(a.C) + ((size_t)frame * H * W1 + xc) * 96 + dl * 12;
-    auto ld_c = [&](int y) -> Vec {
-        if (DPL != 8) return ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y)));
-        const int yc = min(y, H - 1);
-        const v3d_u32x3_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v3d_u32x3_a4*>(Cp12 + (size_t)(YREV ? H - 1 - yc : yc) * W1 * 96));
-        uint32_t r[4] = { unpack12_pair(v.x), unpack12_pair(alignbit(v.y, v.x, 24)), unpack12_pair(alignbit(v.z, v.y, 16)), unpack12_pair(v.z >> 8) };
-        Vec o; vec_repack(o, r); return o;
-    };
-#else
     auto ld_c = [&](int y) -> Vec { return ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y))); };
-#endif
     Vec sq[PF];
 #pragma unroll
     for (int j = 0; j < PF; j++) { cq[j] = ld_c(j); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
@@ -1421,7 +1351,9 @@ __global__ __launch_bounds__(256) void k_ccl_runs(const int16_t* __restrict__ im
 // A thread tests EIGHT consecutive pixels of a row pair (two 16-byte loads + the pair left of them); one wave covers 512
 // columns.  (Round 2's one-pixel-per-thread form launched a million 30-instruction waves per batch: 0.21 ms per 30 frames,
 // bound by wave launch, not by its loads.)
+#ifndef VM_BAND
 #define VM_BAND 16
+#endif
 template <int LEVEL>
 __global__ __launch_bounds__(64) void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ lab)
 {
