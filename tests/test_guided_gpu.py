@@ -130,7 +130,7 @@ def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, b
         one = native.guided_upscale(d, g, r, 1e-3)
     finally:
         native.set_option("gf_fused", 1)
-        native.set_option("gf_band", 270)
+        native.set_option("gf_band", 0)                       # back to auto
         native.set_option("gf_cols", 256)
     assert torch.equal(one, two), f"{int((one != two).sum())} pixels differ, max {float((one - two).abs().max())}"
     if Wg * Hg <= 700 * 400:

@@ -15,7 +15,7 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.2 (gfx950)"; }
 
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 270, 256, 0, 1 };
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 0, 256, 0, 1 };        // gf_band1, gf_band2, gf_tiled, gf_fused, gf_band (0 = auto), gf_cols, corr_gather, corr_fused
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
