@@ -130,7 +130,7 @@ def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, b
         one = native.guided_upscale(d, g, r, 1e-3)
     finally:
         native.set_option("gf_fused", 1)
-        native.set_option("gf_band", 0)                       # back to auto
+        native.set_option("gf_band", 432)                     # the default
         native.set_option("gf_cols", 256)
     assert torch.equal(one, two), f"{int((one != two).sum())} pixels differ, max {float((one - two).abs().max())}"
     if Wg * Hg <= 700 * 400:
@@ -160,3 +160,17 @@ def test_disp16_input_equals_depth_input_bit_for_bit(native, r, fused, tiled):
         native.set_option("gf_tiled", 0)
     assert torch.equal(direct, via_depth)
     assert float(direct.abs().max()) > 1.0
+
+
+def test_a_frames_bits_do_not_depend_on_the_batch_it_shares(native):
+    """the band partition of the fused kernel is fixed by the frame height, not chosen per launch: the same frame filtered alone
+    and as one of five comes out bit-identical (option gf_band = 0, the per-launch optimum, does not promise that)"""
+    import torch
+    rng = np.random.default_rng(77)
+    disp = rng.integers(-16, 64 * 16, (1, 540, 960)).astype(np.int16)
+    guide = rng.integers(0, 256, (1, 1080, 1920), dtype=np.uint8)
+    d1, g1 = native.to_device(disp), native.to_device(guide)
+    alone = native.guided_upscale_batch(d1, g1, 8, 1e-3)
+    five = native.guided_upscale_batch(d1.expand(5, -1, -1).contiguous(), g1.expand(5, -1, -1).contiguous(), 8, 1e-3)
+    for i in range(5):
+        assert torch.equal(five[i], alone[0])

@@ -15,7 +15,12 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.2 (gfx950)"; }
 
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 0, 256, 0, 1 };        // gf_band1, gf_band2, gf_tiled, gf_fused, gf_band (0 = auto), gf_cols, corr_gather, corr_fused
+// gf_band1, gf_band2, gf_tiled, gf_fused, gf_band, gf_cols, corr_gather, corr_fused.
+// gf_band: 432 rows = 5 bands of a 4K frame: 34 frames (one lock-step launch upstream) are 5.98 rounds of the 512 resident
+// workgroups, where round 2's 270 rows were 9.56 (2.56 -> 2.43 ms).  A FIXED height, not the per-launch optimum (value 0):
+// the second stage's sliding sums round differently for a different band origin, and a frame's bits must not depend on how
+// many frames share its launch.
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 432, 256, 0, 1 };
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
