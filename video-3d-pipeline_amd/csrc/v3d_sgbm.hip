@@ -18,8 +18,8 @@
 #include <type_traits>
 
 // ---- experiment switches (tools/build_variant.sh; every default = the product path) ----
-#ifndef V3D_RIL
-#define V3D_RIL 1               // rows of a volume interleaved in groups of V3D_RIL at pixel granularity (1 = plain [H][W1][64])
+#ifndef V3D_C12
+#define V3D_C12 1               // 1: the cost volume C is stored as 12 bits per disparity (96 bytes per pixel, C - P2 <= 25 * 93 < 4096); 0: int16
 #endif
 #ifndef V3D_X_SPLIT
 #define V3D_X_SPLIT 0           // 1: k_hfused's phase 1 (left->right scan, checkpoints) as its own launch k_hscan
@@ -27,9 +27,16 @@
 // (Round 3's timing proxies -- a 12-bit C in each of the three big kernels, an SGM chain step hosted in k_cost, k_hfused's
 //  phase 1 reading an L1- / L2-resident window -- lived here as V3D_X_C12 / V3D_X_COSTCHAIN / V3D_X_P1L2 builds; their numbers
 //  are in DESIGN.md and profiles/r03_experiments/, the code in the history (commit "bench: default batch = one lock-step launch").)
-#define VOL_PX (V3D_RIL * V3D_D)                                   // elements between pixel x and x + 1 of a row
-__host__ __device__ static inline size_t vol_row(int y, int W1) { return ((size_t)(y / V3D_RIL) * W1 * V3D_RIL + (size_t)(y % V3D_RIL)) * V3D_D; }
-__host__ __device__ static inline size_t vol_frame(int H, int W1) { return (size_t)((H + V3D_RIL - 1) / V3D_RIL) * V3D_RIL * W1 * V3D_D; }
+// S (aggregated costs): int16 [H][W1][64] -- offsets in ELEMENTS
+#define VOL_PX V3D_D                                               // elements between pixel x and x + 1 of a row
+__host__ __device__ static inline size_t vol_row(int y, int W1) { return (size_t)y * W1 * V3D_D; }
+__host__ __device__ static inline size_t vol_frame(int H, int W1) { return (size_t)H * W1 * V3D_D; }
+// C (matching costs): [H][W1] pixels of C_PXB bytes -- offsets in BYTES.  With V3D_C12 a pixel is 64 x 12 bits, disparity d at
+// bit 12 d, holding C - P2 (the 5x5 box sum alone: <= 2325); every reader adds P2 back as it unpacks, so the recurrences see the
+// same int16 C as before.  A quarter fewer bytes on each of C's four touches (one write, three reads).
+#define C_PXB (V3D_C12 ? 96 : 128)
+__host__ __device__ static inline size_t c_row(int y, int W1) { return (size_t)y * W1 * C_PXB; }
+__host__ __device__ static inline size_t c_frame(int H, int W1) { return (size_t)H * W1 * C_PXB; }
 
 // ------------------------------------------------------------------------------------------------
 // a-4 (i): x-Sobel pre-filter + raw plane + Birchfield-Tomasi half-sample intervals, both images.
@@ -150,6 +157,43 @@ template <int NP> struct Packer;
 template <> struct Packer<4> { static __device__ __forceinline__ uint4 go(const uint32_t (&r)[4]) { return vec_pack4(r); } };
 template <> struct Packer<2> { static __device__ __forceinline__ uint2 go(const uint32_t (&r)[2]) { return vec_pack2(r); } };
 
+// ---- a lane's view of C: DPL disparities of one pixel.  CRaw is what it fetches, c_unpack turns it into DPL/2 packed int16 pairs ----
+typedef uint32_t v3d_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t v3d_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+template <int DPL> struct CRaw;
+#if V3D_C12
+template <> struct CRaw<8> { typedef v3d_u32x3_a4 type; };      // the lane's 8 x 12 bits: 12 bytes at byte 12 dl of the pixel
+template <> struct CRaw<4> { typedef v3d_u32x2_a4 type; };      // 8 bytes from the dword boundary at or below byte 6 dl: the lane's 48 bits start at bit (dl & 1) * 16
+template <int DPL> __device__ __forceinline__ int c_lane_off(int dl) { return DPL == 8 ? 12 * dl : (6 * dl) & ~3; }
+__device__ __forceinline__ uint32_t unpack12_pair(uint32_t t) { return (t & 0xFFFu) | ((t << 4) & 0x0FFF0000u); }     // bits 0-11 | 12-23 -> two halves
+__device__ __forceinline__ uint4 c_unpack(const v3d_u32x3_a4& v, int, uint32_t P2pk)
+{
+    return make_uint4(pk_add(unpack12_pair(v.x), P2pk), pk_add(unpack12_pair(alignbit(v.y, v.x, 24)), P2pk),
+                      pk_add(unpack12_pair(alignbit(v.z, v.y, 16)), P2pk), pk_add(unpack12_pair(v.z >> 8), P2pk));
+}
+__device__ __forceinline__ uint2 c_unpack(const v3d_u32x2_a4& v, int dl, uint32_t P2pk)
+{
+    const uint32_t sh = (uint32_t)(dl & 1) * 16u;
+    const uint32_t lo = alignbit(v.y, v.x, sh), hi = v.y >> sh;                 // the lane's 48 bits: lo, hi[15:0]
+    return make_uint2(pk_add(unpack12_pair(lo), P2pk), pk_add(unpack12_pair(alignbit(hi, lo, 24)), P2pk));
+}
+#else
+template <> struct CRaw<8> { typedef v3d_u32x4 type; };
+template <> struct CRaw<4> { typedef v3d_u32x2 type; };
+template <int DPL> __device__ __forceinline__ int c_lane_off(int dl) { return dl * DPL * 2; }
+__device__ __forceinline__ uint4 c_unpack(const v3d_u32x4& v, int, uint32_t) { return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 c_unpack(const v3d_u32x2& v, int, uint32_t) { return make_uint2(v.x, v.y); }
+#endif
+// streaming (once-read) load of a lane's field; p = pixel base + c_lane_off
+// load of a lane's field; p = pixel base + c_lane_off.  STREAM: non-temporal (k_vdd: every line is touched by one load).  With
+// 96-byte pixels k_hfused's consecutive pixel loads share cache lines (pixel k starts at 96 k): there the plain load keeps the
+// line in L1 for the next pixel (measured: 4.52 -> 4.30 ms per 34 frames; the same switch costs k_vdd 1.5 %)
+template <int DPL, bool STREAM> __device__ __forceinline__ typename CRaw<DPL>::type c_load(const unsigned char* p)
+{
+    if (V3D_NT && STREAM) return __builtin_nontemporal_load(reinterpret_cast<const typename CRaw<DPL>::type*>(p));
+    return *reinterpret_cast<const typename CRaw<DPL>::type*>(p);
+}
+
 // (Tried and dropped: letting the vertical SGM path ride along in this kernel -- the lane layout is k_chain's,
 // but the unbanded kernel it needs has too few waves to gain anything.)
 template <int LPC>
@@ -157,7 +201,7 @@ template <int LPC>
 #define V3D_COST_WAVES 6
 #endif
 __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __restrict__ rec,
-                                              int W, int H, int W1, int band_h, int P2, int16_t* __restrict__ C, int xcd_order)
+                                              int W, int H, int W1, int band_h, int P2, unsigned char* __restrict__ C, int xcd_order)
 {
     typedef CostGeo<LPC> G;
     constexpr int EP = G::EP, NP = G::NP, COLS = G::COLS, OUT = G::OUT, NREC = G::NREC;
@@ -181,7 +225,8 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
     const int ys = byi * band_h, ye = min(ys + band_h, H);
     const int f = bzi;
     const uint32_t* rf = reinterpret_cast<const uint32_t*>(rec + (size_t)f * H * W);   // 4 dwords per pixel
-    int16_t* Cf = C + (size_t)f * vol_frame(H, W1);
+    unsigned char* Cf = C + (size_t)f * c_frame(H, W1);
+    static_assert(!V3D_C12 || LPC == 8, "the 12-bit store packs a lane's 8 disparities into one 12-byte field");
 
     const int xrc = min(max(xr0 - 2 + col, 0), W1 - 1);        // clamped cost-region column of this lane
     // staged record i <-> image column xr0 - 1 + i; reversed element k = NREC-1 - i.  d = EP*dq + j reads record
@@ -228,7 +273,7 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
     };
     // every VMEM instruction of the row loop is issued unconditionally (v3d_common.h: raw buffer access): threads
     // that stage nothing, halo columns and the warm-up rows are switched off through an out-of-range offset
-    const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)(vol_frame(H, W1) * 2u));
+    const __amdgpu_buffer_rsrc_t rs_rec = buf_rsrc(rf, (uint32_t)H * W * 16u), rs_c = buf_rsrc(Cf, (uint32_t)c_frame(H, W1));
     const uint32_t la = ld_any ? ld_a * 4u : V3D_BUF_OOB, lb = ld_any ? ld_b * 4u : V3D_BUF_OOB;   // + row offset < 2^31: bit 31 survives
     auto fetch = [&](int k) -> uint2 {
         const uint32_t ro = (uint32_t)min(max(ys - 2 + min(k, nrows - 1), 0), H - 1) * W * 16u;
@@ -243,11 +288,11 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
 
     uint32_t ring[5][NP], vs[NP];                               // last five rows' horizontal sums + their running sum
 #pragma unroll
-    for (int j = 0; j < NP; j++) { vs[j] = pk_bcast(P2);         // P2 rides in the running sum: C = P2 + box sum
+    for (int j = 0; j < NP; j++) { vs[j] = V3D_C12 ? 0u : pk_bcast(P2);    // int16 C: P2 rides in the running sum (C = P2 + box sum); 12-bit C: the box sum alone
 #pragma unroll
         for (int i = 0; i < 5; i++) ring[i][j] = 0u; }
     // C store offsets: per-thread part (out-of-range marker for halo columns) + uniform row part
-    const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * VOL_PX + EP * dq) * 2u : V3D_BUF_OOB;
+    const uint32_t st_col = out_col ? (uint32_t)((xr0 - 2 + col) * C_PXB + c_lane_off<EP>(dq)) : V3D_BUF_OOB;
 
     for (int k10 = 0; k10 < nrows; k10 += 10) {
 #pragma unroll
@@ -296,8 +341,19 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
             }
 #pragma unroll
             for (int j = 0; j < NP; j++) { vs[j] += h[j] - ring[slot][j]; ring[slot][j] = h[j]; }   // add row k, drop row k - 5
-            const uint32_t st_row = k >= 4 ? (uint32_t)(vol_row(ys + k - 4, W1) * 2u) : V3D_BUF_OOB;     // uniform
-            buf_store_stream(rs_c, __builtin_elementwise_add_sat(st_col, st_row), Packer<NP>::go(vs));   // saturating: marker + marker stays out of range
+            const uint32_t st_row = k >= 4 ? (uint32_t)c_row(ys + k - 4, W1) : V3D_BUF_OOB;     // uniform
+            const uint32_t st_off = __builtin_elementwise_add_sat(st_col, st_row);                        // saturating: marker + marker stays out of range
+#if V3D_C12
+            {   // 8 x 12 bits -> three dwords, one 12-byte store per lane (a wave's store covers 8 whole pixels: 768 contiguous bytes)
+                uint32_t t[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) t[j] = (vs[j] & 0xFFFu) | ((vs[j] >> 4) & 0xFFF000u);        // halves <= 2325: 24 bits per pair
+                const v3d_u32x3_a4 pk = { t[0] | (t[1] << 24), (t[1] >> 8) | (t[2] << 16), (t[2] >> 16) | (t[NP - 1] << 8) };
+                __builtin_amdgcn_raw_buffer_store_b96(pk, rs_c, st_off, 0, V3D_NT ? 2 : 0);
+            }
+#else
+            buf_store_stream(rs_c, st_off, Packer<NP>::go(vs));
+#endif
         }
       }
     }
@@ -314,7 +370,7 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
 //   MODE 2: S + L -> LDS -> winner-take-all / uniqueness / sub-pixel / right-view keys (last direction)
 // ------------------------------------------------------------------------------------------------
 struct ChainArgs {
-    const int16_t* C; int16_t* S;
+    const unsigned char* C; int16_t* S;
     int W1, H, W, nframes;
     int P1, P2;
     int uniq;                 // uniquenessRatio
@@ -472,7 +528,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
     else if (XS > 0) { tlo = max(0, H - 1 - c1); thi = min(H, W1 + H - 1 - c0); }
     else { tlo = max(0, c0 - (W1 - 1)); thi = min(H, c1 + 1); }
 
-    const int16_t* Cf = a.C + (size_t)frame * vol_frame(H, W1) + dl * DPL;
+    const unsigned char* Cf = a.C + (size_t)frame * c_frame(H, W1) + c_lane_off<DPL>(dl);
     int16_t* Sf = a.S + (size_t)frame * vol_frame(H, W1) + dl * DPL;
     const int x0 = HORIZ ? 0 : (XS == 0 ? cc : (XS > 0 ? cc - (H - 1) : cc));
 
@@ -480,10 +536,10 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
         if (HORIZ) { x = XS > 0 ? t : W1 - 1 - t; y = cc; }
         else { y = YREV ? H - 1 - t : t; x = x0 + XS * t; }
     };
-    auto elem_off = [&](int t) -> int {
+    auto pix_off = [&](int t) -> int {                         // pixel index of step t inside the frame
         int x, y; pos(t, x, y);
         x = min(max(x, 0), W1 - 1);
-        return (int)(vol_row(y, W1) + (size_t)x * VOL_PX);
+        return y * W1 + x;
     };
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
@@ -494,12 +550,12 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
     for (int i = 0; i < NP; i++) p[i] = 0;
     uint32_t delta = P2pk;                                    // out-of-image predecessor: L = 0, min = 0
 
-    Vec cq[PF], sq[PF];
+    typename CRaw<DPL>::type cq[PF]; Vec sq[PF];
 #pragma unroll
     for (int j = 0; j < PF; j++) {
-        const int o = elem_off(min(tlo + j, thi - 1));
-        cq[j] = *reinterpret_cast<const Vec*>(Cf + o);
-        if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + o);
+        const size_t o = (size_t)pix_off(min(tlo + j, thi - 1));
+        cq[j] = *reinterpret_cast<const typename CRaw<DPL>::type*>(Cf + o * C_PXB);
+        if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + o * VOL_PX);
     }
 
     unsigned char* myS = sS + (MODE == 2 ? wib * 64 * WTA_ROWB : 0);
@@ -511,13 +567,13 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
             const int t = tb + jj;
             if (t < thi) {
                 uint32_t cv[NP], sv[NP], L[NP];
-                vec_unpack<NP>(cq[j], cv);
+                vec_unpack<NP>(c_unpack(cq[j], dl, P2pk), cv);
                 if (MODE != 0) vec_unpack<NP>(sq[j], sv);
-                const int o = elem_off(t);
+                const size_t o = (size_t)pix_off(t) * VOL_PX;
                 {   // refill this queue slot with step t + PF
-                    const int on = elem_off(min(t + PF, thi - 1));
-                    cq[j] = *reinterpret_cast<const Vec*>(Cf + on);
-                    if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + on);
+                    const size_t on = (size_t)pix_off(min(t + PF, thi - 1));
+                    cq[j] = *reinterpret_cast<const typename CRaw<DPL>::type*>(Cf + on * C_PXB);
+                    if (MODE != 0) sq[j] = *reinterpret_cast<const Vec*>(Sf + on * VOL_PX);
                 }
                 uint32_t nd = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
                 bool active = cvalid;
@@ -567,24 +623,20 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a)
 // Cost: L_left is computed twice (+1 path of VALU), C is read twice, S once, never written.
 // ------------------------------------------------------------------------------------------------
 template <int DPL> struct HfC {
-    typedef typename VecT<DPL>::type Vec;
-    // pointer to the lane's disparities of pixel (row, x = 0) and the load of pixel x
-    static __device__ __forceinline__ const char* base(const int16_t* C, int frame, int H, int W1, int row, int dl)
+    typedef typename CRaw<DPL>::type Raw;
+    // pointer to the lane's field of pixel (row, x = 0) and the load of pixel x
+    static __device__ __forceinline__ const unsigned char* base(const unsigned char* C, int frame, int H, int W1, int row, int dl)
     {
-        return reinterpret_cast<const char*>(C + (size_t)frame * vol_frame(H, W1) + vol_row(row, W1) + dl * DPL);
+        return C + (size_t)frame * c_frame(H, W1) + c_row(row, W1) + c_lane_off<DPL>(dl);
     }
-    static __device__ __forceinline__ Vec load(const char* b, int x, int dl)
-    {
-        return ld_stream(reinterpret_cast<const Vec*>(b + (size_t)x * (VOL_PX * 2)));
-    }
+    static __device__ __forceinline__ Raw load(const unsigned char* b, int x) { return c_load<DPL, !V3D_C12>(b + (size_t)x * C_PXB); }
 };
 
 // ---------------- phase 1: left -> right over blocks 0 .. nblk-2, checkpoint at every block start ----------------
 template <int DPL>
-__device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nblk, int dl, uint32_t P1pk, uint32_t P2pk)
+__device__ __forceinline__ void hf_phase1(const unsigned char* Crow, uint32_t* ck, int nblk, int dl, uint32_t P1pk, uint32_t P2pk)
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, K = 64 / DPL;
-    typedef typename VecT<DPL>::type Vec;
     const bool first_lane = dl == 0, last_lane = dl == LPP - 1;
     uint32_t p[NP];
 #pragma unroll
@@ -593,13 +645,13 @@ __device__ __forceinline__ void hf_phase1(const char* Crow, uint32_t* ck, int nb
     const int xend = (nblk - 1) * K;                       // the last block is recomputed in phase 2 anyway
     for (int xb = 0; xb < xend; xb += K) {
         // a block's K loads go out back to back: per row stream the DRAM sees one 2-KB burst, not 16 scattered lines
-        Vec cb[K];
+        typename HfC<DPL>::Raw cb[K];
 #pragma unroll
-        for (int jj = 0; jj < K; jj++) cb[jj] = HfC<DPL>::load(Crow, xb + jj, dl);
+        for (int jj = 0; jj < K; jj++) cb[jj] = HfC<DPL>::load(Crow, xb + jj);
 #pragma unroll
         for (int jj = 0; jj < K; jj++) {
             uint32_t cv[NP], L[NP];
-            vec_unpack<NP>(cb[jj], cv);
+            vec_unpack<NP>(c_unpack(cb[jj], dl, P2pk), cv);
             delta = chain_step<NP, LPP>(p, delta, cv, L, P1pk, P2pk, first_lane, last_lane);
 #pragma unroll
             for (int i = 0; i < NP; i++) p[i] = L[i];
@@ -644,7 +696,7 @@ __global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __rest
     const int frame = work / groups, grp = work - frame * groups;
     const int c0 = grp * PPW, c1 = min(c0 + PPW, H) - 1;
     const int cc = min(c0 + sub, c1);
-    const char* Crow = HfC<DPL>::base(a.C, frame, H, W1, cc, dl);
+    const unsigned char* Crow = HfC<DPL>::base(a.C, frame, H, W1, cc, dl);
     const int16_t* Srow = a.S + (size_t)frame * vol_frame(H, W1) + vol_row(cc, W1) + dl * DPL;
     uint32_t* ck = ckpt + ((size_t)frame * groups + grp) * nblk * NP * 64 + lane;         // [blk][reg][lane]; delta is recomputed
     if (PH & 1) hf_phase1<DPL>(Crow, ck, nblk, dl, P1pk, P2pk);
@@ -666,11 +718,11 @@ __global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __rest
         //  phase 2's C + S + checkpoints).  So phase 2 without the WTA streams at the box's read ceiling, phase 1 adds
         //  its 8.2 GB at ~4.5 TB/s and the WTA tail 0.4-0.6 ms that no amount of load scheduling hides: the kernel is
         //  bound by the memory system (24.5 GB at 5.0 TB/s, VALU 56 % busy), not by latency exposure or occupancy.)
-        Vec cvv[K], svv[K];
+        typename HfC<DPL>::Raw craw[K]; Vec cvv[K], svv[K];
 #pragma unroll
         for (int j = 0; j < K; j++) {
             const int xj = min(x0 + j, W1 - 1);
-            cvv[j] = HfC<DPL>::load(Crow, xj, dl);
+            craw[j] = HfC<DPL>::load(Crow, xj);
             svv[j] = ld_stream(reinterpret_cast<const Vec*>(Srow + (size_t)xj * VOL_PX));
         }
         uint32_t p[NP], delta = P2pk;
@@ -686,6 +738,7 @@ __global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __rest
 #pragma unroll
         for (int j = 0; j < K; j++) {                          // forward recompute of the left path inside the block
             uint32_t cv[NP];
+            cvv[j] = c_unpack(craw[j], dl, P2pk);              // unpacked once, as it arrives; the backward pass re-uses the int16 form
             vec_unpack<NP>(cvv[j], cv);
             delta = chain_step<NP, LPP>(p, delta, cv, L0[j], P1pk, P2pk, first_lane, last_lane);
 #pragma unroll
@@ -768,7 +821,7 @@ __global__ __launch_bounds__(256, 8) void k_hscan(ChainArgs a, uint32_t* __restr
 #define VDD_SPIN_SLACK 4096
 
 struct VddArgs {
-    const int16_t* C; int16_t* S;
+    const unsigned char* C; int16_t* S;
     int W1, H, nframes, nstrips;
     int P1, P2;
     uint32_t seq;
@@ -813,7 +866,12 @@ template <int DPL, bool YREV>
 __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD = two workgroups per CU: the second hides the hand-off latency
 {
     constexpr int NP = DPL / 2, LPP = 64 / DPL, PPW = DPL, PXS = 16 * PPW;   // PXS = columns per strip (64 / 128)
-    constexpr int PF = DPL == 8 ? 1 : 4;         // C prefetch depth in rows (the 64-VGPR budget of two workgroups per CU binds at DPL = 8)
+#ifndef V3D_VDD_PF8
+#define V3D_VDD_PF8 2
+#endif
+    // C prefetch depth in rows.  The 64-VGPR budget of two workgroups per CU binds at DPL = 8: one row with int16 C (4 registers per
+    // row), two rows with the 12-bit C (3 registers per row; measured 3.34 -> 3.23 ms per 34 frames); the bottom-up pass also queues S
+    constexpr int PF = DPL == 8 ? (YREV || !V3D_C12 ? 1 : V3D_VDD_PF8) : 4;
     typedef typename VecT<DPL>::type Vec;
     // per-pixel exchanged state: LPP lanes x {L1 (NP dwords), L3 (NP dwords)} + per pixel {delta1, delta3}
     __shared__ Vec sL1[2][PXS + 2][LPP];
@@ -831,7 +889,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
     const bool ragged = __builtin_amdgcn_readfirstlane((strip + 1) * PXS > W1);   // this strip sticks out of the image
     const int xc = min(x, W1 - 1);
     const size_t fbase = (size_t)frame * vol_frame(H, W1);
-    const int16_t* Cp = a.C + fbase + (size_t)xc * VOL_PX + dl * DPL;
+    const unsigned char* Cp = a.C + (size_t)frame * c_frame(H, W1) + (size_t)xc * C_PXB + c_lane_off<DPL>(dl);
     int16_t* Sp = a.S + fbase + (size_t)xc * VOL_PX + dl * DPL;
 
     const uint32_t P1pk = pk_bcast(a.P1), P2pk = pk_bcast(a.P2);
@@ -858,9 +916,10 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
 #pragma unroll
     for (int i = 0; i < NP; i++) p2[i] = 0u;
 
-    Vec cq[PF];
-    auto rowof = [&](int y) -> size_t { const int yc = min(y, H - 1); return vol_row(YREV ? H - 1 - yc : yc, W1); };
-    auto ld_c = [&](int y) -> Vec { return ld_stream(reinterpret_cast<const Vec*>(Cp + rowof(y))); };
+    typename CRaw<DPL>::type cq[PF];
+    auto rowy = [&](int y) -> int { const int yc = min(y, H - 1); return YREV ? H - 1 - yc : yc; };
+    auto rowof = [&](int y) -> size_t { return vol_row(rowy(y), W1); };
+    auto ld_c = [&](int y) { return c_load<DPL, true>(Cp + c_row(rowy(y), W1)); };
     Vec sq[PF];
 #pragma unroll
     for (int j = 0; j < PF; j++) { cq[j] = ld_c(j); if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(j))); }
@@ -882,7 +941,10 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                 //         strips' granules, polled AFTER the barrier so the other 14 waves compute meanwhile ----
                 uint32_t cv[NP], p1[NP], p3[NP];
                 uint32_t sold[NP];
-                vec_unpack<NP>(cq[j], cv);
+                // (12-bit C: unpacking the NEXT row at the end of this one, off the path between the barrier and the recurrences
+                //  the neighbour strips wait for, was measured: 3.32 -> 3.49 ms per 34 frames -- one more row of raw fields and
+                //  an unpacked row live across the barrier cost more than the ~18 ops they move)
+                vec_unpack<NP>(c_unpack(cq[j], dl, P2pk), cv);
                 if (YREV) vec_unpack<NP>(sq[j], sold);
                 cq[j] = ld_c(y + PF);
                 if (YREV) sq[j] = ld_stream(reinterpret_cast<const Vec*>(Sp + rowof(y + PF)));
@@ -945,6 +1007,7 @@ __global__ __launch_bounds__(1024, 8) void k_vdd(VddArgs a)      // 8 waves/SIMD
                     for (int i = 0; i < NP; i++) { o[i] = pk_add_sat(pk_add_sat(L1[i], L2[i]), L3[i]); if (YREV) o[i] = pk_add_sat(o[i], sold[i]); }
                     st_stream(reinterpret_cast<Vec*>(Sp + rowof(y)), Packer<NP>::go(o));
                 }
+
             }
         }
     }
@@ -1455,6 +1518,16 @@ static int launch_speckles(int16_t* img, int W, int H, int frames, int newVal, i
     return V3D_OK;
 }
 
+// parity-test export of C as int16 (v3d_sgbm_debug_cost_volume): 8 lanes per pixel, 8 disparities each
+__global__ __launch_bounds__(256) void k_c_export(const unsigned char* __restrict__ C, size_t npx, int P2, int16_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, px = i >> 3;
+    const int dl = (int)(i & 7);
+    if (px >= npx) return;
+    const uint4 v = c_unpack(*reinterpret_cast<const typename CRaw<8>::type*>(C + px * C_PXB + c_lane_off<8>(dl)), dl, pk_bcast(P2));
+    *reinterpret_cast<uint4*>(out + px * V3D_D + 8 * dl) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1464,7 +1537,8 @@ struct v3d_sgbm {
     int P1, P2, ftzero, uniq, d12;
     int dpl;                                    // disparities per lane in k_chain (4 or 8)
     uint4* rec;
-    int16_t *C, *S;
+    unsigned char* C;                           // cost volume, C_PXB bytes per pixel
+    int16_t* S;
     uint32_t* wta;                              // WTA records, one per pixel
     uint32_t* ckpt;                             // k_hfused checkpoints
     unsigned long long* gran;                   // k_vdd edge granules
@@ -1632,7 +1706,7 @@ extern "C" int v3d_sgbm_create(const v3d_sgbm_params* prm, int device, int maxW,
     h->bytes = 0;
     int rc = 0;
     rc |= ws_alloc(&h->rec, px, &h->bytes);
-    rc |= ws_alloc(&h->C, vol, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
+    rc |= ws_alloc(&h->C, c_frame(maxH, maxW - V3D_D) * maxB, &h->bytes);   rc |= ws_alloc(&h->S, vol, &h->bytes);
     rc |= ws_alloc(&h->wta, px, &h->bytes); rc |= ws_alloc(&h->labels, px * 3, &h->bytes);
     {   // checkpoints: per frame, per wave (DPL rows), per K-pixel block: 64 lanes x (DPL/2 + 1) dwords
         const int W1m = maxW - V3D_D;
@@ -1724,7 +1798,7 @@ static void launch_vdd(v3d_sgbm* h, int n, int W1, int H, bool rev, hipStream_t 
     for (int f0 = 0; f0 < n; f0 += per) {
         VddArgs v;
         const int nf = n - f0 < per ? n - f0 : per;
-        v.C = h->C + (size_t)f0 * vol_frame(H, W1); v.S = h->S + (size_t)f0 * vol_frame(H, W1);
+        v.C = h->C + (size_t)f0 * c_frame(H, W1); v.S = h->S + (size_t)f0 * vol_frame(H, W1);
         v.W1 = W1; v.H = H; v.nframes = nf; v.nstrips = v3d_cdiv(W1, 16 * dpl); v.P1 = h->P1; v.P2 = h->P2;
         v.seq = (h->vdd_seq++) & 0xFFFFFu;
         if (v.seq == 0) {                                   // the 20-bit launch sequence wrapped: sweep the stale tags (once per 2^20 launches)
@@ -1943,7 +2017,10 @@ extern "C" int v3d_sgbm_debug_cost_volume(v3d_sgbm* h, const uint8_t* l, const u
     int16_t dummy;
     int rc = run_sgbm(h, l, r, 1, W, H, pitch, 0, &dummy, 1, (hipStream_t)stream);
     if (rc) return rc;
-    V3D_HIP_CHECK(hipMemcpyAsync(C_out, h->C, (size_t)(W - V3D_D) * H * V3D_D * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    // the export is int16 [H][W-64][64] with P2 folded in, whatever the storage form
+    const size_t npx = (size_t)(W - V3D_D) * H;
+    hipLaunchKernelGGL(k_c_export, dim3((unsigned)((npx * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->C, npx, h->P2, C_out);
+    V3D_LAUNCH_CHECK();
     return V3D_OK;
 }
 extern "C" int v3d_sgbm_debug_raw(v3d_sgbm* h, const uint8_t* l, const uint8_t* r, int W, int H, int pitch, int16_t* out, int16_t* S_out, void* stream)
