@@ -107,7 +107,7 @@ int v3d_sgbm_set_option(v3d_sgbm* h, const char* key, int value);
 int v3d_sgbm_get_option(const v3d_sgbm* h, const char* key, int* value);
 /* library-wide switches of the handle-less entry points: "gf_fused" 1/0 (guided filter as one launch with a/b kept in LDS /
    as two sweeps with a/b through HBM: same bits), "gf_band" (rows per workgroup of the fused kernel, default 432; 0 = chosen per launch from its round count -- then a frame's last bit may depend on the batch size), "gf_cols" 256/512 (its
-   strip width), "gf_band1", "gf_band2" (rows per workgroup of the two sweeps), "gf_tiled" 0/1 (force the LDS-tiled guided
+   strip width), "gf_int1" 1/0 (int16 disparity + exact 2x: stage 1 of the fused kernel in exact integers / in f64: same bits), "gf_band1", "gf_band2" (rows per workgroup of the two sweeps), "gf_tiled" 0/1 (force the LDS-tiled guided
    kernel), "corr_fused" 1/0 (1x9 correlation as one gather-GEMM launch with the warped features staged in LDS / as a warp
    kernel + a GEMM kernel: same bits), "corr_gather" 0/1 (register-only gather-GEMM) */
 int v3d_set_option(const char* key, int value);

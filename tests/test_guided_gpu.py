@@ -174,3 +174,27 @@ def test_a_frames_bits_do_not_depend_on_the_batch_it_shares(native):
     five = native.guided_upscale_batch(d1.expand(5, -1, -1).contiguous(), g1.expand(5, -1, -1).contiguous(), 8, 1e-3)
     for i in range(5):
         assert torch.equal(five[i], alone[0])
+
+
+@pytest.mark.parametrize("Wlo,Hlo,r,band", [(320, 180, 8, 432), (117, 75, 8, 16), (150, 48, 4, 40), (9, 10, 8, 432), (500, 350, 8, 100)])
+def test_integer_stage1_is_bit_identical_to_the_f64_stage1(native, oracle, Wlo, Hlo, r, band):
+    """int16 disparity + exact 2x: stage 1 of the fused kernel runs in exact integers (sum of 256 p and of g * 256 p fit int32);
+    the four window sums are the values the f64 path holds, so the output has the same bits -- and meets the oracle"""
+    import torch
+    rng = np.random.default_rng(Wlo * 3 + Hlo)
+    d = rng.integers(-16, 1024, (2, Hlo, Wlo)).astype(np.int16)
+    d[rng.random(d.shape) < 0.1] = -16
+    g = rng.integers(0, 256, (2, 2 * Hlo, 2 * Wlo), dtype=np.uint8)
+    dd, gg = native.to_device(d), native.to_device(g)
+    try:
+        native.set_option("gf_band", band)
+        native.set_option("gf_int1", 0)
+        a = native.guided_upscale_batch(dd, gg, r, 1e-3)
+        native.set_option("gf_int1", 1)
+        b = native.guided_upscale_batch(dd, gg, r, 1e-3)
+    finally:
+        native.set_option("gf_int1", 1)
+        native.set_option("gf_band", 432)
+    assert torch.equal(a, b)
+    want = oracle.guided_upscale(oracle.disp_to_depth(d[0]), g[0], r, 1e-3)
+    assert _rel_err(b[0].cpu().numpy().astype(np.float64), want).max() <= RTOL

@@ -15,12 +15,12 @@ void v3d_set_error(const char* fmt, ...)
 extern "C" const char* v3d_last_error(void) { return g_err; }
 extern "C" const char* v3d_version(void) { return "libv3d_hip 0.2 (gfx950)"; }
 
-// gf_band1, gf_band2, gf_tiled, gf_fused, gf_band, gf_cols, corr_gather, corr_fused.
+// gf_band1, gf_band2, gf_tiled, gf_fused, gf_band, gf_cols, gf_int1, corr_gather, corr_fused.
 // gf_band: 432 rows = 5 bands of a 4K frame: 34 frames (one lock-step launch upstream) are 5.98 rounds of the 512 resident
 // workgroups, where round 2's 270 rows were 9.56 (2.56 -> 2.43 ms).  A FIXED height, not the per-launch optimum (value 0):
 // the second stage's sliding sums round differently for a different band origin, and a frame's bits must not depend on how
 // many frames share its launch.
-v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 432, 256, 0, 1 };
+v3d_lib_options g_v3d_opt = { 90, 270, 0, 1, 432, 256, 1, 0, 1 };
 
 extern "C" int v3d_set_option(const char* key, int value)
 {
@@ -34,6 +34,7 @@ extern "C" int v3d_set_option(const char* key, int value)
         if (value != 256 && value != 512) { v3d_set_error("option gf_cols: 256 or 512"); return V3D_ERR_ARG; }
         g_v3d_opt.gf_cols = value;
     }
+    else if (!strcmp(key, "gf_int1")) g_v3d_opt.gf_int1 = value != 0;
     else if (!strcmp(key, "corr_gather")) g_v3d_opt.corr_gather = value != 0;
     else if (!strcmp(key, "corr_fused")) g_v3d_opt.corr_fused = value != 0;
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }
@@ -49,6 +50,7 @@ extern "C" int v3d_get_option(const char* key, int* value)
     else if (!strcmp(key, "gf_tiled")) *value = g_v3d_opt.gf_tiled;
     else if (!strcmp(key, "gf_fused")) *value = g_v3d_opt.gf_fused;
     else if (!strcmp(key, "gf_cols")) *value = g_v3d_opt.gf_cols;
+    else if (!strcmp(key, "gf_int1")) *value = g_v3d_opt.gf_int1;
     else if (!strcmp(key, "corr_gather")) *value = g_v3d_opt.corr_gather;
     else if (!strcmp(key, "corr_fused")) *value = g_v3d_opt.corr_fused;
     else { v3d_set_error("unknown option %s", key); return V3D_ERR_ARG; }

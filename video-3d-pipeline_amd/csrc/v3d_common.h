@@ -19,6 +19,7 @@ struct v3d_lib_options {
     int gf_fused;             // 1: single-launch guided filter (a/b rows handed from stage-1 to stage-2 waves through LDS), 0: two sweeps through HBM
     int gf_band;              // rows per workgroup of the fused kernel (default 432); 0 = per launch: fewest rounds x (band + 4r)
     int gf_cols;              // strip width of the fused kernel: 256 (8 waves, two workgroups per CU) or 512 (16 waves, one)
+    int gf_int1;              // 1: int16 disparity + exact 2x -> stage 1 of the fused kernel in exact integers (same bits)
     int corr_gather;          // 1: register-only gather-GEMM correlation (bit-identical, blends every position twice, slower)
     int corr_fused;           // 1: gather-GEMM through LDS for the 1x9 pattern (warped features never touch HBM), 0: warp kernel + GEMM kernel
 };

@@ -13,6 +13,7 @@
 // zero-depth regions q is ~1e-4 while the window holds values ~40, and the 1e-3 *relative* parity bar cannot be
 // met there with f32 cancellation in cov/var and in box(b).
 #include "v3d_common.h"
+#include <type_traits>
 
 // 1/x to full double precision: v_rcp_f64 seed (~26 bits) + two Newton steps (5 instructions instead of the
 // ~30 of an IEEE division; the last-ulp difference is far inside the 1e-3 parity bar)
@@ -398,16 +399,28 @@ __global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, in
 // f64 operations per output) is three times as long as a wave that does one pixel pair.  The pair form spreads exactly that
 // chain over all lanes; what remains is its instruction count.  (Kernel kept out of the tree; numbers in DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
-template <int RR, int COLS, typename TD>
+// I1 (int16 disparity in, exact 2x upscale): stage 1's four window sums are EXACT INTEGERS.  The disparity is d/16 with d <= 1023
+// and the x2 bilinear weights are {1,3}/4 per axis, so P = 256 p = sum w d (w in {1,3,9}) is an integer <= 16368; over a 17 x 17
+// window sum P < 2^23 and sum g P < 2^31.  The ring holds (P << 8 | g) in ONE register per row (17 instead of 34 + 5), the
+// vertical sums are four int32, the row pair's sums cross the lanes as one int4 per column (16 bytes instead of 24), and the
+// horizontal phase adds integers three at a time (v_add3_u32).  The a/b algebra converts the four exact sums to f64 -- the very
+// values the f64 sums of the general path hold (they are exact there too) -- so the output is bit-identical to it.
+template <int RR, int COLS, typename TD, bool I1>
 __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ depth_lo, int Wlo, int Hlo,
                                                 const uint8_t* __restrict__ guide, int W, int H, double eps, int band_h,
                                                 float* __restrict__ out, size_t depth_stride, size_t guide_stride)
 {
     static_assert(RR % 2 == 0, "pairs must not straddle the strip's halo boundaries");
+    static_assert(!I1 || std::is_same<TD, int16_t>::value, "the integer stage 1 takes the int16 disparity");
     constexpr int R = 2 * RR + 1, NOUT = COLS - 4 * RR, HP = COLS / 2;      // HP pixel pairs per row
     static_assert(COLS == 256 || COLS == 512, "strip width");
-    __shared__ __attribute__((aligned(16))) double sV1[2][2][2][COLS];        // [buffer][row of the pair][sum p | sum g*p][column]
-    __shared__ __attribute__((aligned(16))) int2 sVi[2][2][COLS];             // [buffer][row][column] {sum g, sum g*g}
+    // stage 1's row-pair sums: general path {sum p, sum g*p} f64 planes + {sum g, sum g*g} int2; I1: one int4 {sum g, sum g*g, sum P, sum g*P}
+    constexpr int S1D = 2 * 2 * 2 * COLS * 8, S1I = 2 * 2 * COLS * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char sS1[I1 ? 2 * 2 * COLS * 16 : S1D + S1I];
+    double (*sV1)[2][2][COLS] = reinterpret_cast<double (*)[2][2][COLS]>(sS1);               // [buffer][row of the pair][sum p | sum g*p][column]
+    int2 (*sVi)[2][COLS] = reinterpret_cast<int2 (*)[2][COLS]>(sS1 + (I1 ? 0 : S1D));         // [buffer][row][column] {sum g, sum g*g}
+    int4 (*sVq)[2][COLS] = reinterpret_cast<int4 (*)[2][COLS]>(sS1);                          // I1: [buffer][row][column]
+    (void)sV1; (void)sVi; (void)sVq;
     __shared__ __attribute__((aligned(16))) double sAB[2][2][2][COLS];        // [buffer][row][a | b][column]   stage 1 -> stage 2
     __shared__ __attribute__((aligned(16))) double sV2[2][2][2][COLS];        // [buffer][row][sum a | sum b][column]
     {   // frame of the batch
@@ -428,6 +441,110 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
     __syncthreads();
 
     if (role == 0) {
+      if constexpr (I1) {
+        // ================= stage 1, exact integer sums (int16 disparity, exact 2x) =================
+        const bool col_ok = gx >= 0 && gx < W;
+        const bool pair_in = 2 * hq >= RR && 2 * hq < COLS - RR;      // a/b columns of the strip
+        const bool px0 = pair_in && hgx >= 0 && hgx < W, px1 = pair_in && hgx + 1 >= 0 && hgx + 1 < W;
+        // x2 bilinear source columns and weights (quarters): even x = 2k: (k-1, k) x (1, 3); odd: (k, k+1) x (3, 1)
+        const int kx = gx >> 1;
+        const int bxa = min(max((gx & 1) ? kx : kx - 1, 0), Wlo - 1), bxb = min(max((gx & 1) ? kx + 1 : kx, 0), Wlo - 1);
+        const int wxa = (gx & 1) ? 3 : 1, wxb = 4 - wxa;
+        uint32_t ring[R];                        // (P << 8) | g of the last 2r+1 rows
+        int vg = 0, vgg = 0, vP = 0, vgP = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) ring[j] = 0u;
+        struct RowIn { int g, a0, a1, b0, b1; bool in; };
+        const int gxc = min(max(gx, 0), W - 1);
+        auto fetch_row = [&](int tt) -> RowIn {        // unconditional loads from clamped addresses
+            RowIn q;
+            const int e = ya - 2 * RR + tt;                                      // input row entering the window
+            q.in = col_ok && e >= 0 && e < H && tt < nrows;
+            const int ec = min(max(e, 0), H - 1), ky = ec >> 1;
+            q.g = guide[(size_t)ec * W + gxc];
+            const TD* ra = depth_lo + (size_t)min(max((ec & 1) ? ky : ky - 1, 0), Hlo - 1) * Wlo;
+            const TD* rb = depth_lo + (size_t)min(max((ec & 1) ? ky + 1 : ky, 0), Hlo - 1) * Wlo;
+            q.a0 = max((int)ra[bxa], 0); q.a1 = max((int)ra[bxb], 0); q.b0 = max((int)rb[bxa], 0); q.b1 = max((int)rb[bxb], 0);   // depth.py:374: <= 0 -> 0
+            return q;
+        };
+        RowIn nx[2] = { fetch_row(0), fetch_row(1) };
+        for (int p0 = 0; p0 < NP; p0 += R) {
+#pragma unroll
+            for (int sp = 0; sp < R; sp++) {
+                const int p = p0 + sp;
+                if (p < NP) {                                                    // uniform
+                    int tl = t;
+                    asm volatile("" : "+v"(tl));                                 // (nothing of the horizontal phase hoisted out of the loop)
+                    const int hrow = tl / HP, hq = tl % HP, hgx = gx0 + 2 * hq;
+                    // ---- H1(p-1): window sums of the row pair V1(p-1) left in LDS -> a, b of two pixels -> sAB ----
+                    const int j = p - 1;
+                    if (j >= RR && j < NS && pair_in) {
+                        const int hb = j & 1;
+                        const int y = ya - 3 * RR + 2 * j + hrow;                // centre row of this window
+                        double ab[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
+                        if (y >= 0 && y < H && px0) {
+                            // columns 2hq - r .. 2hq + 1 + r: first (f), the 2r common ones (c), last (l)
+                            const int4* gi = &sVq[hb][hrow][2 * hq - RR];
+                            const int4 f = gi[0], l = gi[2 * RR + 1];
+                            int4 c = make_int4(0, 0, 0, 0);
+#pragma unroll
+                            for (int ch = 1; ch <= 2 * RR; ch += 4) {
+                                int4 u[4];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) if (ch + i <= 2 * RR) u[i] = gi[ch + i];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) if (ch + i <= 2 * RR) { c.x += u[i].x; c.y += u[i].y; c.z += u[i].z; c.w += u[i].w; }
+                                asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w) :: "memory");
+                            }
+                            const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
+                            const int cx0 = min(hgx + RR, W - 1) - max(hgx - RR, 0) + 1, cx1 = min(hgx + 1 + RR, W - 1) - max(hgx + 1 - RR, 0) + 1;
+                            const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
+#pragma unroll
+                            for (int n = 0; n < 2; n++) {
+                                const int4 e = n ? l : f;
+                                const double inv = n ? invb : inva;
+                                const double s0 = (double)(c.z + e.z) * (1.0 / 256.0), s1 = (double)(c.w + e.w) * (1.0 / 256.0);   // sum p, sum g*p: exact
+                                const double mI = (double)(c.x + e.x) * (inv * (1.0 / 255.0)), mp = s0 * inv;
+                                const double mII = (double)(c.y + e.y) * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
+                                const double var = fma(-mI, mI, mII), cov = fma(-mI, mp, mIp);
+                                const double a = cov * gf_rcp(var + eps);
+                                ab[n][0] = a; ab[n][1] = fma(-a, mI, mp);
+                            }
+                            if (!px1) { ab[1][0] = 0.0; ab[1][1] = 0.0; }
+                        }
+                        // rows and columns outside the image hand ZERO a/b to stage 2 (its windows count in-image pixels only)
+                        const v3d_f64x2 va2 = { ab[0][0], ab[1][0] }, vb2 = { ab[0][1], ab[1][1] };
+                        *reinterpret_cast<v3d_f64x2*>(&sAB[hb][hrow][0][2 * hq]) = va2;
+                        *reinterpret_cast<v3d_f64x2*>(&sAB[hb][hrow][1][2 * hq]) = vb2;
+                    }
+                    // ---- V1(p): two input rows enter the column's window ----
+                    if (p < NS) {
+                        const int tA = 2 * p;
+                        const RowIn cur[2] = { nx[0], nx[1] };
+                        nx[0] = fetch_row(tA + 2); nx[1] = fetch_row(tA + 3);
+                        const bool emit = p >= RR;                               // uniform
+#pragma unroll
+                        for (int rr = 0; rr < 2; rr++) {
+                            const int slot = (2 * sp + rr) % R;                  // compile-time ring slot
+                            int gn = 0, Pn = 0;
+                            if (cur[rr].in) {
+                                gn = cur[rr].g;
+                                const int e = ya - 2 * RR + tA + rr;             // (in the image here)
+                                const int wya = (e & 1) ? 3 : 1;
+                                Pn = wya * (wxa * cur[rr].a0 + wxb * cur[rr].a1) + (4 - wya) * (wxa * cur[rr].b0 + wxb * cur[rr].b1);   // 256 p
+                            }
+                            const int go = (int)(ring[slot] & 0xFFu), Po = (int)(ring[slot] >> 8);
+                            ring[slot] = ((uint32_t)Pn << 8) | (uint32_t)gn;
+                            vg += gn - go; vgg += gn * gn - go * go;
+                            vP += Pn - Po; vgP += gn * Pn - go * Po;
+                            if (emit) sVq[p & 1][rr][t] = make_int4(vg, vgg, vP, vgP);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+      } else {
         // ================= stage 1: guide + depth -> a, b (k_gfm<1>'s arithmetic) =================
         const bool col_ok = gx >= 0 && gx < W;
         const double sx = (double)Wlo / (double)W, sy = (double)Hlo / (double)H;
@@ -571,6 +688,7 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                 }
             }
         }
+      }
     } else {
         // ================= stage 2: a, b -> q (k_gfm<2>'s arithmetic) =================
         const bool pair_out = 2 * hq >= 2 * RR && 2 * hq < COLS - 2 * RR;           // output columns of the strip
@@ -682,11 +800,17 @@ static void launch_gff(const TD* depth_lo, int Wlo, int Hlo, const uint8_t* guid
     }
     if (g_v3d_opt.gf_cols == 512) {        // 512-column strips, 16 waves, one workgroup per CU: half the strip-halo recompute
         const dim3 grid(v3d_cdiv(W, 512 - 4 * RR), v3d_cdiv(H, band), n);
-        hipLaunchKernelGGL((k_gff<RR, 512, TD>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+        hipLaunchKernelGGL((k_gff<RR, 512, TD, false>), grid, dim3(1024), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
         return;
     }
     const dim3 grid(v3d_cdiv(W, 256 - 4 * RR), v3d_cdiv(H, band), n);
-    hipLaunchKernelGGL((k_gff<RR, 256, TD>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+    if constexpr (std::is_same<TD, int16_t>::value) {
+        if (g_v3d_opt.gf_int1 && W == 2 * Wlo && H == 2 * Hlo) {          // int16 disparity, exact 2x: stage 1 in exact integers
+            hipLaunchKernelGGL((k_gff<RR, 256, TD, true>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_gff<RR, 256, TD, false>), grid, dim3(512), 0, st, depth_lo, Wlo, Hlo, guide, W, H, eps, band, out, depth_stride, guide_stride);
 }
 
 template <int RR, typename TD>
