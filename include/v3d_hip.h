@@ -178,7 +178,10 @@ int v3d_guided_upscale_batch(const float* depth_lo, int Wlo, int Hlo, size_t dep
 /* the same filter fed with the matcher's int16 disparity (x16, <= 0 = invalid): depth.py:341 `.astype(float32)/16.0` and
    depth.py:374 `disparity[disparity <= 0] = 0` happen as the values are loaded, so the stereo-only pipeline
    (sgbm -> upscale) never writes or re-reads the float32 depth plane.  Bit-identical to v3d_disp_to_depth followed by
-   v3d_guided_upscale_batch.  Frame f at disp16 + f*disp_stride (int16 elements). */
+   v3d_guided_upscale_batch.  Frame f at disp16 + f*disp_stride (int16 elements).
+   Domain: disparities up to 16 * 113 = 1820 (this build's matcher, numDisparities = 64, never exceeds 1023).  For an exact 2x
+   upscale the filter's first stage then runs in exact int32 sums (sum of g * 256 p over a window stays below 2^31); a caller
+   feeding larger values must switch that off first: v3d_set_option("gf_int1", 0). */
 int v3d_guided_upscale_disp16_batch(const int16_t* disp16, int Wlo, int Hlo, size_t disp_stride, const uint8_t* guide,
                                     int Whi, int Hhi, size_t guide_stride, int n, int r, float eps, float* out,
                                     void* ws, void* stream);
