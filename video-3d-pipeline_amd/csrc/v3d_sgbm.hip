@@ -347,8 +347,11 @@ __global__ __launch_bounds__(512, V3D_COST_WAVES) void k_cost(const uint4* __res
             {   // 8 x 12 bits -> three dwords, one 12-byte store per lane (a wave's store covers 8 whole pixels: 768 contiguous bytes)
                 uint32_t t[NP];
 #pragma unroll
-                for (int j = 0; j < NP; j++) t[j] = (vs[j] & 0xFFFu) | ((vs[j] >> 4) & 0xFFF000u);        // halves <= 2325: 24 bits per pair
-                const v3d_u32x3_a4 pk = { t[0] | (t[1] << 24), (t[1] >> 8) | (t[2] << 16), (t[2] >> 16) | (t[NP - 1] << 8) };
+                for (int j = 0; j < NP; j++)                                                           // halves < 4096: 24 bits per pair = (vs & 0xFFF) | (vs >> 4 & ~0xFFF):
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t[j]) : "s"(0xFFFu), "v"(vs[j]), "v"(vs[j] >> 4));   //   one shift + one bit-field insert (the compiler's own form takes three ops)
+                // four 3-byte values -> three dwords, a v_perm_b32 each
+                const v3d_u32x3_a4 pk = { __builtin_amdgcn_perm(t[1], t[0], 0x04020100u), __builtin_amdgcn_perm(t[2], t[1], 0x05040201u),
+                                          __builtin_amdgcn_perm(t[NP - 1], t[2], 0x06050402u) };
                 __builtin_amdgcn_raw_buffer_store_b96(pk, rs_c, st_off, 0, V3D_NT ? 2 : 0);
             }
 #else
