@@ -36,7 +36,10 @@ __device__ __forceinline__ int gray_of(int b, int g, int r) { return (r * 9798 +
 // (128 + 8 BGR pixels when unsqueezing, 256 otherwise) is staged through LDS with coalesced dword loads:
 // per-tap byte loads at a 3-byte stride straight from HBM ran at 0.3 TB/s.
 // GRAY: write luma only; else write the BGR triple.
-#define SBS_ROWS 8    // rows per workgroup: the per-row work is tiny, one workgroup per row was bound by dispatch
+#ifndef SBS_ROWS
+#define SBS_ROWS 8
+#endif
+//    // rows per workgroup: the per-row work is tiny, one workgroup per row was bound by dispatch
 // Unsqueezing, a thread computes the output PAIR (2m, 2m+1): the two 8-tap windows (source pixels m-4..m+3 with the
 // frac-0.75 taps, m-3..m+4 with the frac-0.25 taps) overlap in 7 of 8 pixels, so 27 LDS bytes serve both instead of
 // 48; a block covers 512 output pixels of one eye row.  Without unsqueeze a thread copies one pixel (256 per block).

@@ -46,7 +46,9 @@ __host__ __device__ static inline size_t c_frame(int H, int W1) { return (size_t
 // from LDS, and the horizontal differences of the two older rows ride along in registers -- 2 byte loads per pixel
 // instead of the 14 a one-row-per-workgroup version issues (that one was bound by its VMEM instruction count).
 // The records trail the gradients by one row so that both LDS exchanges of a step share a single barrier.
+#ifndef PF_BAND
 #define PF_BAND 64
+#endif
 __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2,
                                                    int W, int H, int pitch, size_t frame_stride, int ft,
                                                    uint4* __restrict__ rec)
