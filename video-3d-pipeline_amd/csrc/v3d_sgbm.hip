@@ -18,6 +18,10 @@
 #include <type_traits>
 
 // ---- experiment switches (tools/build_variant.sh; every default = the product path) ----
+#ifndef V3D_CK_NT
+#define V3D_CK_NT 1            // k_hfused's checkpoints written / read with streaming hints: they are re-read ~1 ms later, long after L2 has turned
+                               // over, and as plain accesses they evict the C lines consecutive 96-byte pixels share (4.41 -> 4.22 ms per 34 frames)
+#endif
 #ifndef V3D_C12
 #define V3D_C12 1               // 1: the cost volume C is stored as 12 bits per disparity (96 bytes per pixel, C - P2 <= 25 * 93 < 4096); 0: int16
 #endif
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ i
             dm[im] = d0[im]; d0[im] = de; r0[im] = (ve >> (8 * im)) & 0xFF;
         }
         if (y > ya && t >= 2 && t <= 253 && x < W)
-            rec[((size_t)f * H + (y - 1)) * W + x] = make_uint4(out[0], out[1], out[2], out[3]);
+            st_stream(rec + ((size_t)f * H + (y - 1)) * W + x, make_uint4(out[0], out[1], out[2], out[3]));   // 1.1 GB per launch, read by the NEXT kernel: streaming (0.353 -> 0.325 ms)
     }
 }
 
@@ -663,7 +667,7 @@ __device__ __forceinline__ void hf_phase1(const unsigned char* Crow, uint32_t* c
         }
         uint32_t* c = ck + (size_t)(xb / K + 1) * NP * 64;
 #pragma unroll
-        for (int i = 0; i < NP; i++) c[i * 64] = p[i];
+        for (int i = 0; i < NP; i++) { if (V3D_CK_NT) __builtin_nontemporal_store(p[i], c + i * 64); else c[i * 64] = p[i]; }
     }
 }
 
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(256, 4) void k_hfused(ChainArgs a, uint32_t* __rest
         if (blk > 0) {
             const uint32_t* c = ck + (size_t)blk * NP * 64;
 #pragma unroll
-            for (int i = 0; i < NP; i++) p[i] = c[i * 64];
+            for (int i = 0; i < NP; i++) p[i] = V3D_CK_NT ? __builtin_nontemporal_load(c + i * 64) : c[i * 64];
             delta = chain_delta<NP, LPP>(p, P2pk);
         }
         uint32_t L0[K][NP];
