@@ -53,6 +53,18 @@ def test_library_reads_no_environment():
     assert lib.v3d_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.v3d_last_error()
     assert lib.v3d_set_option(b"gf_band1", 90) == 0
     assert lib.v3d_sgbm_set_option(None, b"lockstep", 1) == -1            # null handle is an argument error, not a crash
+    # every library-wide switch reads back (v3d_get_option), bad values are refused and leave the setting alone
+    import ctypes as C
+    v = C.c_int(-7)
+    for key, good, bad in ((b"gf_band", 128, 3), (b"gf_cols", 512, 300), (b"gf_int1", 0, None), (b"gf_fused", 0, None),
+                           (b"corr_fused", 0, None), (b"gf_band1", 60, 1 << 20)):
+        assert lib.v3d_get_option(key, C.byref(v)) == 0
+        before = v.value
+        assert lib.v3d_set_option(key, good) == 0 and lib.v3d_get_option(key, C.byref(v)) == 0 and v.value == good
+        if bad is not None:
+            assert lib.v3d_set_option(key, bad) == -1 and lib.v3d_get_option(key, C.byref(v)) == 0 and v.value == good
+        assert lib.v3d_set_option(key, before) == 0
+    assert lib.v3d_get_option(b"no_such_switch", C.byref(v)) == -1
 
 
 def test_product_does_not_import_the_oracle():

@@ -429,7 +429,7 @@ def test_speckle_run_lists_extremes(native, oracle, W, H):
                 mismatch_report(got, want, f"{name} {W}x{H} size<={max_size} diff<={max_diff}")
 
 
-@pytest.mark.parametrize("W,H", [(70, 5), (257, 33), (300, 31), (1920, 64), (2500, 40), (4000, 12)])
+@pytest.mark.parametrize("W,H", [(70, 5), (257, 33), (300, 31), (1920, 64), (2048, 8), (2050, 6), (2500, 40), (4000, 12), (4096, 4), (4100, 3)])
 def test_lrcheck_median_row_march_equals_tiles_and_oracle(native, oracle, W, H):
     """the L-R check + 3x3 median as a row march over full-width bands (default; 8 or 16 pixels per thread and row) against
     the 128 x 16 tile form and the oracle: band edges (30-row bands), image borders, widths that end mid-thread-stride, the raw
