@@ -113,8 +113,8 @@ def test_batch_with_strided_guides(native, oracle):
 @pytest.mark.parametrize("Wg,Hg,r,band", [(640, 360, 8, 270), (233, 151, 8, 16), (301, 97, 4, 40), (257, 33, 8, 8), (19, 21, 8, 270),
                                           (500, 301, 8, 64), (3840, 2160, 8, 270)])
 def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, band, cols):
-    """k_gff (a/b handed stage-1 -> stage-2 waves through LDS, the default) performs the two-sweep kernels' arithmetic in
-    the same order: the outputs are IDENTICAL, for every band height (warm-up rows, ragged last band, bands shorter than
+    """k_gff (a/b handed stage-1 -> stage-2 waves through LDS, the default) performs the two-sweep kernels' arithmetic (window
+    sums re-associated as pair sums since round 3): the outputs agree to the last float32 bit or one, for every band height (warm-up rows, ragged last band, bands shorter than
     the window), odd sizes (scalar stores, half-filled row pairs) and strips that end mid-image; and both meet the oracle"""
     import torch
     depth, _ = _case(Wg + band, max(Wg // 2, 8), max(Hg // 2, 8))
@@ -132,7 +132,10 @@ def test_fused_kernel_equals_two_sweeps_bit_for_bit(native, oracle, Wg, Hg, r, b
         native.set_option("gf_fused", 1)
         native.set_option("gf_band", 432)                     # the default
         native.set_option("gf_cols", 256)
-    assert torch.equal(one, two), f"{int((one != two).sum())} pixels differ, max {float((one - two).abs().max())}"
+    # round 3: the fused kernel forms a window as aligned pair sums minus one column, the sweeps as a running sum of columns -- the
+    # same f64 value up to rounding (~1e-16 relative), which the float32 output absorbs except for rare last-bit flips
+    diff = (one.double() - two.double()).abs() / two.double().abs().clamp_min(1e-6 * float(two.abs().max()))
+    assert float(diff.max()) <= 2e-7, f"{int((one != two).sum())} pixels differ, max rel {float(diff.max()):.3e}"
     if Wg * Hg <= 700 * 400:
         want = oracle.guided_upscale(depth, guide, r, 1e-3)
         assert _rel_err(one.cpu().numpy().astype(np.float64), want).max() <= RTOL

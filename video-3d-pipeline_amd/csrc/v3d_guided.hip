@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, in
 // Each role keeps ONE ring (<= 128 VGPRs, four waves per SIMD, two workgroups per CU); putting both rings into one
 // thread needs ~180 VGPRs and halves the occupancy of a kernel that lives on its waves covering each other's LDS and
 // barrier stalls.  All hand-offs are double-buffered LDS rows, so a step costs ONE workgroup barrier: in phase p
-// stage 1 runs H1(p-1) then V1(p), stage 2 runs H2(p-3) then V2(p-2).  The arithmetic (operation order included) is
-// that of the two-sweep kernels: results are bit-identical.
+// stage 1 runs H1(p-1) then V1(p), stage 2 runs H2(p-3) then V2(p-2).  The arithmetic is that of the two-sweep kernels; since
+// round 3 the window sums are re-associated (aligned pair sums, see PAIR SUMS below): equal to rounding, not by construction bit for bit.
 // HBM traffic: guide + depth_lo (x 256/224 strip overlap, + 4r warm-up rows per band) in, q out.
 // Measured on 30 4K frames: 2.15 ms against 2.72 ms for the two sweeps (VALU pipe 61 % busy, LDS pipe 62 %: the kernel is
 // bound by its ~170 mostly-f64 instructions per pixel, no longer by HBM).  Tried, no gain: a wave-uniform fast path that
@@ -399,6 +399,20 @@ __global__ __launch_bounds__(256) void k_gfm(const TD* __restrict__ depth_lo, in
 // f64 operations per output) is three times as long as a wave that does one pixel pair.  The pair form spreads exactly that
 // chain over all lanes; what remains is its instruction count.  (Kernel kept out of the tree; numbers in DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
+// value of the lane's pair partner (lane ^ 1): two DPP moves for the halves of a double
+__device__ __forceinline__ double gf_partner(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), V3D_DPP_QUAD(1, 0, 3, 2), 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), V3D_DPP_QUAD(1, 0, 3, 2), 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int gf_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, V3D_DPP_QUAD(1, 0, 3, 2), 0xF, 0xF, true); }
+
+// PAIR SUMS (round 3).  The horizontal phases are bound by the LDS pipe: a 2r+2-column window costs r+1 16-byte reads per plane
+// and thread, ~1400 LDS cycles per workgroup and step.  The vertical phase therefore also leaves, next to every column sum, the
+// sum of each ALIGNED column pair (own value + the lane partner's, one DPP exchange): a window that starts on an even column is
+// r+1 pair sums, and the two outputs of a thread are that total minus the one column each of them does not cover --
+// r+1 8-byte reads + 2 singles instead of r+1 16-byte reads, r+2 adds instead of 2r+1.
 // I1 (int16 disparity in, exact 2x upscale): stage 1's four window sums are EXACT INTEGERS.  The disparity is d/16 with d <= 1023
 // and the x2 bilinear weights are {1,3}/4 per axis, so P = 256 p = sum w d (w in {1,3,9}) is an integer <= 16368; over a 17 x 17
 // window sum P < 2^23 and sum g P < 2^31.  The ring holds (P << 8 | g) in ONE register per row (17 instead of 34 + 5), the
@@ -423,6 +437,9 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
     (void)sV1; (void)sVi; (void)sVq;
     __shared__ __attribute__((aligned(16))) double sAB[2][2][2][COLS];        // [buffer][row][a | b][column]   stage 1 -> stage 2
     __shared__ __attribute__((aligned(16))) double sV2[2][2][2][COLS];        // [buffer][row][sum a | sum b][column]
+    __shared__ __attribute__((aligned(16))) double sP2[2][2][2][COLS / 2];    // [buffer][row][sum a | sum b][aligned column pair]
+    __shared__ __attribute__((aligned(16))) int4 sPq[I1 ? 2 : 1][2][I1 ? COLS / 2 : 1];   // I1: [buffer][row][aligned column pair]
+    (void)sPq;
     {   // frame of the batch
         const size_t f = blockIdx.z, n4 = (size_t)W * H;
         depth_lo += f * depth_stride; guide += f * guide_stride; out += f * n4;
@@ -483,17 +500,18 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                         const int y = ya - 3 * RR + 2 * j + hrow;                // centre row of this window
                         double ab[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
                         if (y >= 0 && y < H && px0) {
-                            // columns 2hq - r .. 2hq + 1 + r: first (f), the 2r common ones (c), last (l)
-                            const int4* gi = &sVq[hb][hrow][2 * hq - RR];
-                            const int4 f = gi[0], l = gi[2 * RR + 1];
+                            // columns 2hq - r .. 2hq + 1 + r = the r + 1 aligned pairs hq - r/2 .. hq + r/2: their total, then each
+                            // output drops the one column it does not cover (output 0 the last, output 1 the first)
+                            const int4* gp = &sPq[hb][hrow][hq - RR / 2];
+                            const int4 f = sVq[hb][hrow][2 * hq - RR], l = sVq[hb][hrow][2 * hq + RR + 1];
                             int4 c = make_int4(0, 0, 0, 0);
 #pragma unroll
-                            for (int ch = 1; ch <= 2 * RR; ch += 4) {
-                                int4 u[4];
+                            for (int ch = 0; ch <= RR; ch += 3) {
+                                int4 u[3];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) if (ch + i <= 2 * RR) u[i] = gi[ch + i];
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) u[i] = gp[ch + i];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) if (ch + i <= 2 * RR) { c.x += u[i].x; c.y += u[i].y; c.z += u[i].z; c.w += u[i].w; }
+                                for (int i = 0; i < 3; i++) if (ch + i <= RR) { c.x += u[i].x; c.y += u[i].y; c.z += u[i].z; c.w += u[i].w; }
                                 asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w) :: "memory");
                             }
                             const int cy = min(y + RR, H - 1) - max(y - RR, 0) + 1;
@@ -501,11 +519,11 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                             const double inva = gf_rcp((double)(cx0 * cy)), invb = cx1 == cx0 ? inva : gf_rcp((double)(cx1 * cy));
 #pragma unroll
                             for (int n = 0; n < 2; n++) {
-                                const int4 e = n ? l : f;
+                                const int4 e = n ? f : l;                    // the column this output does NOT cover
                                 const double inv = n ? invb : inva;
-                                const double s0 = (double)(c.z + e.z) * (1.0 / 256.0), s1 = (double)(c.w + e.w) * (1.0 / 256.0);   // sum p, sum g*p: exact
-                                const double mI = (double)(c.x + e.x) * (inv * (1.0 / 255.0)), mp = s0 * inv;
-                                const double mII = (double)(c.y + e.y) * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
+                                const double s0 = (double)(c.z - e.z) * (1.0 / 256.0), s1 = (double)(c.w - e.w) * (1.0 / 256.0);   // sum p, sum g*p: exact
+                                const double mI = (double)(c.x - e.x) * (inv * (1.0 / 255.0)), mp = s0 * inv;
+                                const double mII = (double)(c.y - e.y) * (inv * (1.0 / 65025.0)), mIp = s1 * (inv * (1.0 / 255.0));
                                 const double var = fma(-mI, mI, mII), cov = fma(-mI, mp, mIp);
                                 const double a = cov * gf_rcp(var + eps);
                                 ab[n][0] = a; ab[n][1] = fma(-a, mI, mp);
@@ -537,7 +555,11 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                             ring[slot] = ((uint32_t)Pn << 8) | (uint32_t)gn;
                             vg += gn - go; vgg += gn * gn - go * go;
                             vP += Pn - Po; vgP += gn * Pn - go * Po;
-                            if (emit) sVq[p & 1][rr][t] = make_int4(vg, vgg, vP, vgP);
+                            if (emit) {
+                                sVq[p & 1][rr][t] = make_int4(vg, vgg, vP, vgP);
+                                const int4 ps = make_int4(vg + gf_partner(vg), vgg + gf_partner(vgg), vP + gf_partner(vP), vgP + gf_partner(vgP));
+                                if (!(t & 1)) sPq[p & 1][rr][t >> 1] = ps;
+                            }
                         }
                     }
                     __syncthreads();
@@ -714,27 +736,24 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                         const int y = ya - 4 * RR + 2 * j + hrow;
                         if (j >= 2 * RR && j < NS && px0 && y < yb) {
                             const int hb = j & 1;
-                            // one plane at a time, window sums folded at once: four live values per plane (stage 2 sits at the
-                            // 128-VGPR edge with its two 34-register rings)
+                            // per plane: the total of the r + 1 aligned pair sums hq - r/2 .. hq + r/2 (columns 2hq - r .. 2hq + r + 1), then
+                            // output 0 drops the last column, output 1 the first
                             double wa[2], wb[2];
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
-                                const v3d_f64x2* d = reinterpret_cast<const v3d_f64x2*>(&sV2[hb][hrow][q][0]) + (hq - RR / 2);
-                                double f = 0.0, l = 0.0, c = 0.0;
+                                const double* d = &sP2[hb][hrow][q][hq - RR / 2];
+                                const double f = sV2[hb][hrow][q][2 * hq - RR], l = sV2[hb][hrow][q][2 * hq + RR + 1];
+                                double c = 0.0;
 #pragma unroll
-                                for (int ch = 0; ch <= RR; ch += 2) {
-                                    v3d_f64x2 w[2];
+                                for (int ch = 0; ch <= RR; ch += 3) {
+                                    double w[3];
 #pragma unroll
-                                    for (int i = 0; i < 2; i++) if (ch + i <= RR) w[i] = d[ch + i];
+                                    for (int i = 0; i < 3; i++) if (ch + i <= RR) w[i] = d[ch + i];
 #pragma unroll
-                                    for (int i = 0; i < 2; i++) if (ch + i <= RR) {
-                                        if (ch + i == 0) { f = w[i].x; c = w[i].y; }
-                                        else if (ch + i == RR) { c += w[i].x; l = w[i].y; }
-                                        else { c += w[i].x; c += w[i].y; }
-                                    }
+                                    for (int i = 0; i < 3; i++) if (ch + i <= RR) c += w[i];
                                     asm volatile("" : "+v"(c) :: "memory");
                                 }
-                                wa[q] = c + f; wb[q] = c + l;
+                                wa[q] = c - l; wb[q] = c - f;
                                 asm volatile("" : "+v"(wa[q]), "+v"(wb[q]) :: "memory");
                             }
                             const double s0a = wa[0], s0b = wb[0], s1a = wa[1], s1b = wb[1];
@@ -766,7 +785,11 @@ __global__ __launch_bounds__(2 * COLS, 4) void k_gff(const TD* __restrict__ dept
                                 const double o0 = r0[slot], o1 = r1[slot];
                                 r0[slot] = n0; r1[slot] = n1;
                                 va += n0 - o0; vb += n1 - o1;
-                                if (emit) { sV2[j & 1][rr][0][tl] = va; sV2[j & 1][rr][1][tl] = vb; }
+                                if (emit) {
+                                    sV2[j & 1][rr][0][tl] = va; sV2[j & 1][rr][1][tl] = vb;
+                                    const double pa = va + gf_partner(va), pb = vb + gf_partner(vb);        // aligned pair sums (both lanes of a pair form the same)
+                                    if (!(tl & 1)) { sP2[j & 1][rr][0][tl >> 1] = pa; sP2[j & 1][rr][1][tl >> 1] = pb; }
+                                }
                             }
                         }
                     }
