@@ -230,3 +230,33 @@ def test_mono_blend_known_answers(oracle):
     assert np.array_equal(b, want.astype(np.float32)) and b.min() >= 0 and b.max() <= 0.7 * 63 + 0.3 * 64 + 1e-4
     inv = d16 == -16
     assert np.array_equal(b[inv] > 0, (0.3 * ((m - lo) / (hi - lo) * 64) > 0.7)[inv])   # invalid (-1.0) pixels: the mono term decides
+
+
+def test_unsqueeze_against_a_float64_lanczos4_and_bt601(oracle):
+    """independent restatement in floating point (no shared code, no fixed-point tables): cv2.resize(INTER_LANCZOS4) maps
+    output x to source fx = (x + 0.5) / 2 - 0.5, weights L(t) = sinc(t) sinc(t / 4) on the 8 taps floor(fx) - 3 .. + 4,
+    normalised, borders replicated; cvtColor luma = 0.299 R + 0.587 G + 0.114 B.  The oracle's 2^11 fixed-point taps and 15-bit luma
+    must agree with it within one level everywhere (phases, tap order and border handling pinned; the last-bit rounding is not)"""
+    rng = np.random.default_rng(11)
+    from scipy.ndimage import gaussian_filter
+    sbs = np.clip(gaussian_filter(rng.uniform(0, 255, (6, 96, 3)), (0, 1.2, 0)) * 1.3 - 30, 0, 255).astype(np.uint8)
+    left, right = oracle.split_sbs(sbs, True)
+
+    def lanczos4_x2(half):                                   # half: [H, w, 3] uint8 -> [H, 2w, 3] float64
+        H, w, _ = half.shape
+        out = np.zeros((H, 2 * w, 3))
+        for x in range(2 * w):
+            fx = (x + 0.5) * 0.5 - 0.5
+            x0 = int(np.floor(fx))
+            t = fx - x0
+            taps = np.array([np.sinc(t + 3 - i) * np.sinc((t + 3 - i) / 4.0) for i in range(8)])
+            taps /= taps.sum()
+            idx = np.clip(np.arange(x0 - 3, x0 + 5), 0, w - 1)
+            out[:, x] = np.tensordot(taps, half[:, idx].astype(np.float64), axes=(0, 1))
+        return out
+    for got, half in ((left, sbs[:, :48]), (right, sbs[:, 48:])):
+        want = np.clip(lanczos4_x2(half), 0, 255)
+        assert np.abs(got.astype(np.float64) - want).max() <= 1.0
+    gray = oracle.bgr_to_gray(left)
+    want = left[..., 2] * 0.299 + left[..., 1] * 0.587 + left[..., 0] * 0.114
+    assert np.abs(gray.astype(np.float64) - want).max() <= 1.0
